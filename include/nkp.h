@@ -1,0 +1,154 @@
+/* nkp.h -- C ABI of the MI355X-native sparse solve path (libnkp_hip.so).
+ *
+ * This is the drop-in boundary for the one thing the reference delegates to SuperLU_DIST:
+ * "factor A once, then solve A x = b for each tracer right-hand side".  Every entry point
+ * names the reference call site it replaces (paths relative to /root/reference):
+ *
+ *   nkp_create        <- dCreate_CompCol_Matrix_dist + set_default_options_dist +
+ *                        ScalePermstructInit + LUstructInit + pdgssvx_ABglobal(nrhs=0)
+ *                        src/solve_ABglobal.c:327-353  (factor-only call :353)
+ *   nkp_create_dist   <- dCreate_CompRowLoc_Matrix_dist + pdgssvx(nrhs=0)
+ *                        src/solve_ABdist.c:482-483, 518 (row block m_loc/fst_row :141-144)
+ *   nkp_solve         <- pdgssvx_ABglobal(options.Fact=FACTORED, nrhs=1): B in, X out in the
+ *                        same buffer, berr out, info as return code
+ *                        src/solve_ABglobal.c:363, 393-395;  src/solve_ABdist.c:571
+ *   nkp_destroy       <- Destroy_CompCol_Matrix_dist, Destroy_LU, ScalePermstructFree,
+ *                        LUstructFree, superlu_gridexit   src/solve_ABglobal.c:412-424
+ *   nkp_spmv          <- pdgsmv_AXglobal, the SpMV inside SuperLU's refinement loop
+ *                        src/SuperLU_brief_tree.txt:21-22
+ *   nkp_precond_apply <- pdgstrs_Bglobal (the triangular-solve phase)
+ *                        src/SuperLU_brief_tree.txt:17
+ *
+ * Conventions (mirroring the reference): 0 = success, non-zero = failure; diagnostics go to
+ * stderr prefixed "(rank)"; all indices 0-based; CSR with sorted, duplicate-free rows
+ * (src/matrix.c:3826-3832).  Unlike SuperLU (which takes ownership of the arrays and frees
+ * them in Destroy_*_Matrix_dist) nkp_create COPIES the caller's arrays to the device and
+ * never frees or keeps host pointers.
+ *
+ * Plain C types only; no torch / HIP types in any signature.  Device pointers are passed
+ * as void* and must belong to the device the solver was created on.
+ */
+#ifndef NKP_H
+#define NKP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NKP_VERSION 1
+
+typedef struct nkp_solver nkp_solver;
+
+enum nkp_precond {
+   NKP_PRECOND_NONE = 0,
+   NKP_PRECOND_COLUMN_JACOBI = 1,   /* exact solve of every water-column block (= column-ILU(0):
+                                       zero fill outside the column's band)                   */
+   NKP_PRECOND_MULTILEVEL = 3       /* column blocks as smoother inside an aggregation hierarchy */
+};
+
+enum nkp_krylov { NKP_KRYLOV_FGMRES = 0, NKP_KRYLOV_BICGSTAB = 1 };
+
+/* return codes of nkp_solve (SuperLU's `info` analogue) */
+enum {
+   NKP_OK = 0,
+   NKP_NOT_CONVERGED = 1,    /* max_iters reached; x holds the best iterate, NOT written by the CLIs */
+   NKP_BREAKDOWN = 2,
+   NKP_EINVAL = -1,
+   NKP_ENOMEM = -2,
+   NKP_EDEVICE = -3,         /* HIP runtime failure / no gfx950 device */
+   NKP_ESINGULAR = -4,       /* zero pivot inside a water-column block */
+   NKP_ECOMM = -5
+};
+
+typedef struct nkp_options {
+   int struct_size;      /* = sizeof(nkp_options), ABI guard                                  */
+   int precond;          /* enum nkp_precond                                                  */
+   int krylov;           /* enum nkp_krylov                                                   */
+   int restart;          /* FGMRES restart length m                                           */
+   int max_iters;        /* total Krylov iterations allowed per right-hand side               */
+   double rtol;          /* stop when ||b - A x||_2 <= rtol * ||b||_2 (true residual)         */
+   double atol;          /* ... or <= atol                                                    */
+   int device;           /* HIP device ordinal; -1 = leave the current device                 */
+   int verbose;          /* the reference's dbg_lvl: 0 silent, 1 progress, 2 per-iteration    */
+   int rank;             /* printed as the "(rank)" message prefix (reference `iam`)          */
+   int reorth;           /* 0 = one classical Gram-Schmidt pass, 1 = two passes (default)     */
+   int ml_levels;        /* multilevel: max levels (0 = automatic)                            */
+   int ml_smooth;        /* multilevel: smoothing sweeps per level per half-cycle             */
+   int reserved[8];
+} nkp_options;
+
+int nkp_default_options (nkp_options *opt);
+
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int nkp_device_count (void);
+
+/* Setup ("factor") -- host CSR in, device-resident solver out.
+ *   blk_start[nblk+1]: row offsets of the water-column blocks (contiguous, ascending,
+ *   blk_start[0]=0, blk_start[nblk]=n).  Rows of one block are the levels k=0..KMT-1 of one
+ *   (tracer, column) (src/matrix.c:239-251, 778-784).  NULL => every row its own block
+ *   (point Jacobi). */
+int nkp_create (nkp_solver **out, const nkp_options *opt, int64_t n, int64_t nnz,
+                const int32_t *rowptr, const int32_t *colind, const double *val,
+                const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt);
+
+/* Solve nrhs systems; b (host, column-major, leading dimension ldb >= n) is overwritten by x
+ * when the return code is NKP_OK or NKP_NOT_CONVERGED.  berr[r] receives the componentwise
+ * backward error max_i |b-Ax|_i / (|A||x|+|b|)_i like SuperLU's; iters/relres per rhs.
+ * Any of berr/iters/relres may be NULL. */
+int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t ldb,
+               double *berr, int *iters, double *relres);
+
+/* Same, with b and x already resident on the solver's device (x may alias b); x_inout is also
+ * the initial guess when use_guess != 0. */
+int nkp_solve_device (nkp_solver *s, const void *d_b, void *d_x, int use_guess,
+                      double *berr, int *iters, double *relres);
+
+/* y = A x, exposed for parity and roofline tests (host and device flavours). */
+int nkp_spmv (nkp_solver *s, const double *x, double *y);
+int nkp_spmv_device (nkp_solver *s, const void *d_x, void *d_y);
+
+/* z = M^-1 r with the configured preconditioner (host buffers). */
+int nkp_precond_apply (nkp_solver *s, const double *r, double *z);
+
+/* Deterministic device reductions used by the Krylov drivers, exposed for parity tests:
+ * out[j] = sum_i V[j*ld + i] * w[i], j < k   (host buffers). */
+int nkp_multi_dot (nkp_solver *s, const double *V, int64_t ld, int k, const double *w, double *out);
+
+/* Average duration (ms) of `reps` back-to-back launches of one kernel on the solver's stream,
+ * measured with HIP events on that stream.  which: 0 = CSR SpMV, 1 = preconditioner apply,
+ * 2 = one full Krylov iteration body at restart position `arg` (0 <= arg < restart). */
+int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, double *avg_ms);
+
+/* Introspection: key = "n", "nnz", "nblk", "band", "levels", "spmv_bytes", "device_bytes". */
+int64_t nkp_get_int (nkp_solver *s, const char *key);
+
+/* Use an externally owned HIP stream (hipStream_t cast to void*); NULL = the solver's own. */
+int nkp_set_stream (nkp_solver *s, void *hip_stream);
+
+void nkp_destroy (nkp_solver *s);
+
+/* Message of the last failure on this thread ("" if none). */
+const char *nkp_last_error (void);
+
+/* ---- row-distributed flavour (one process per GPU, RCCL over xGMI) --------------------- */
+
+/* 128-byte RCCL unique id, created on rank 0 and broadcast by the caller (torch.distributed,
+ * MPI or a shared file).  Replaces superlu_gridinit (src/solve_ABdist.c:461). */
+int nkp_comm_unique_id (void *id128);
+
+/* Local row block [fst_row, fst_row + m_loc) with GLOBAL column indices, rowptr rebased to 0
+ * -- exactly what dCreate_CompRowLoc_Matrix_dist receives (src/solve_ABdist.c:482-483).
+ * blk_start_loc holds the local block offsets (relative to fst_row, blk_start_loc[nblk_loc] =
+ * m_loc); a water column must not straddle ranks.  Collective over all ranks. */
+int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global, int64_t fst_row,
+                     int64_t m_loc, int64_t nnz_loc, const int32_t *rowptr_loc,
+                     const int32_t *colind_glob, const double *val,
+                     const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt,
+                     int rank, int nranks, const void *id128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

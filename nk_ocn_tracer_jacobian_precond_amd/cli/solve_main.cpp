@@ -1,0 +1,298 @@
+// solve_ABglobal / solve_ABdist -- drop-in executables.
+//
+//   solve_AB* [-D dbg_lvl] [-n nprow[,npcol]] [-v vars] matrix_fname inout_fname
+//
+// Same command line, file contract, message prefix "(rank)" and exit codes as the reference
+// mains (src/solve_ABglobal.c:37-99, 271-431; src/solve_ABdist.c:42-104, 422-612).  The
+// SuperLU_DIST calls are replaced by the C ABI of include/nkp.h:
+//
+//   dCreate_*_Matrix_dist + pdgssvx*(nrhs=0)     -> nkp_create / nkp_create_dist  ("factor")
+//   pdgssvx*(Fact=FACTORED, nrhs=1), B <- X      -> nkp_solve
+//   Destroy_* / superlu_gridexit                 -> nkp_destroy
+//
+// Deliberate differences: -v is required (the reference dereferences
+// NULL without it, solve_ABglobal.c:24,370); a solve that does not converge exits non-zero and
+// does NOT overwrite the tracer variable (the reference ignores SuperLU's info, :395-405);
+// -n is parsed as before but only sizes the rank count of the distributed flavour.
+// Extra knobs come from the environment so legacy invocations keep working:
+//   NKP_RTOL NKP_MAX_ITERS NKP_RESTART NKP_PRECOND(none|column|multilevel) NKP_KRYLOV(fgmres|bicgstab)
+#include <getopt.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "../../include/nkp.h"
+#include "../host/nkp_host.h"
+
+#ifdef NKP_DIST
+static const char *prog_solver = "nkp_create_dist";
+#else
+static const char *prog_solver = "nkp_create";
+#endif
+
+static long nprow, npcol;
+static char *vars = NULL;
+static char *matrix_fname = NULL;
+static char *inout_fname = NULL;
+
+static int parse_cmd_line (int argc, char **argv)
+{
+   const char *usage_msg = "usage: jacobian_precond [-D dbg_lvl] [-n nprow[,npcol]] [-v vars] matrix_fname inout_fname";
+   int opt;
+
+   while ((opt = getopt (argc, argv, "D:n:v:h")) != -1) {
+      switch (opt) {
+      case '?':
+      case 'h':
+         fprintf (stderr, "(%d) %s\n", iam, usage_msg);
+         return 1;
+      case 'D':
+         if (parse_to_int (optarg, &dbg_lvl)) {
+            fprintf (stderr, "(%d) error parsing argument '%s' for option '%c'\n", iam, optarg, opt);
+            return 1;
+         }
+         break;
+      case 'n': {
+            char *first = strtok (optarg, ",");
+            char *second = strtok (NULL, ",");
+            if (parse_to_long (first, &nprow)) {
+               fprintf (stderr, "(%d) error parsing argument '%s' for option '%c'\n", iam, first ? first : "", opt);
+               return 1;
+            }
+            npcol = nprow;
+            if (second && parse_to_long (second, &npcol)) {
+               fprintf (stderr, "(%d) error parsing argument '%s' for option '%c'\n", iam, second, opt);
+               return 1;
+            }
+            break;
+         }
+      case 'v':
+         free (vars);
+         if ((vars = strdup (optarg)) == NULL) {
+            fprintf (stderr, "(%d) malloc failed in parse_cmd_line for vars\n", iam);
+            return 1;
+         }
+         break;
+      default:
+         fprintf (stderr, "(%d) internal error: unhandled option '-%c'\n", iam, opt);
+         return 1;
+      }
+   }
+   if (optind != argc - 2) {
+      fprintf (stderr, "(%d) unexpected number of arguments\n%s\n", iam, usage_msg);
+      return 1;
+   }
+   matrix_fname = argv[optind++];
+   inout_fname = argv[optind++];
+   if (vars == NULL || vars[0] == '\0') {
+      fprintf (stderr, "(%d) no variables given, nothing to solve (-v vars)\n%s\n", iam, usage_msg);
+      return 1;
+   }
+   return 0;
+}
+
+static void trace (const char *what, const char *subname)
+{
+   if (dbg_lvl > 1) {
+      printf ("(%d) %s %s\n", iam, what, subname);
+      fflush (stdout);
+   }
+}
+
+// read each tracer of the group as a [km][jmt][imt] cube and flatten it into B
+// (reference get_B_global, src/solve_ABglobal.c:153-208)
+static int get_B_global (char **vars_per_solve, double *B)
+{
+   const char *subname = "get_B_global";
+   trace ("entering", subname);
+   double ***field_3d = malloc_3d_double (km, jmt, imt);
+   if (field_3d == NULL) {
+      fprintf (stderr, "(%d) malloc failed in %s for field_3d\n", iam, subname);
+      return 1;
+   }
+   for (int t = 0; t < coupled_tracer_cnt; t++) {
+      size_t nelems = 0;
+      if (dbg_lvl)
+         printf ("(%d) reading %s from %s\n", iam, vars_per_solve[t], inout_fname);
+      if (nkp_var_nelems (inout_fname, vars_per_solve[t], &nelems))
+         return 1;
+      if (nelems != (size_t) km * (size_t) jmt * (size_t) imt) {
+         fprintf (stderr, "(%d) %s: variable %s holds %zu values, expected km*jmt*imt = %zu\n", iam, subname, vars_per_solve[t], nelems,
+                  (size_t) km * (size_t) jmt * (size_t) imt);
+         return 1;
+      }
+      if (get_var_3d_double (inout_fname, vars_per_solve[t], field_3d))
+         return 1;
+      nkp_flatten_tracer (t, field_3d, B);
+   }
+   free_3d_double (field_3d);
+   trace ("exiting", subname);
+   return 0;
+}
+
+// re-read each cube (non-ocean values must survive), scatter X into it, write it back in place
+// (reference put_B_global, src/solve_ABglobal.c:212-267)
+static int put_B_global (char **vars_per_solve, double *B)
+{
+   const char *subname = "put_B_global";
+   trace ("entering", subname);
+   double ***field_3d = malloc_3d_double (km, jmt, imt);
+   if (field_3d == NULL) {
+      fprintf (stderr, "(%d) malloc failed in %s for field_3d\n", iam, subname);
+      return 1;
+   }
+   for (int t = 0; t < coupled_tracer_cnt; t++) {
+      if (get_var_3d_double (inout_fname, vars_per_solve[t], field_3d))
+         return 1;
+      nkp_unflatten_tracer (t, B, field_3d);
+      if (dbg_lvl)
+         printf ("(%d) writing %s to %s\n", iam, vars_per_solve[t], inout_fname);
+      if (put_var_3d_double (inout_fname, vars_per_solve[t], field_3d))
+         return 1;
+   }
+   free_3d_double (field_3d);
+   trace ("exiting", subname);
+   return 0;
+}
+
+static void options_from_env (nkp_options *o)
+{
+   const char *e;
+   double d;
+   int i;
+   if ((e = getenv ("NKP_RTOL")) && !parse_to_double ((char *) e, &d)) o->rtol = d;
+   if ((e = getenv ("NKP_MAX_ITERS")) && !parse_to_int ((char *) e, &i)) o->max_iters = i;
+   if ((e = getenv ("NKP_RESTART")) && !parse_to_int ((char *) e, &i)) o->restart = i;
+   if ((e = getenv ("NKP_PRECOND"))) {
+      if (!strcmp (e, "none")) o->precond = NKP_PRECOND_NONE;
+      else if (!strcmp (e, "column")) o->precond = NKP_PRECOND_COLUMN_JACOBI;
+      else if (!strcmp (e, "multilevel")) o->precond = NKP_PRECOND_MULTILEVEL;
+      else fprintf (stderr, "(%d) ignoring unknown NKP_PRECOND '%s'\n", iam, e);
+   }
+   if ((e = getenv ("NKP_KRYLOV"))) {
+      if (!strcmp (e, "fgmres")) o->krylov = NKP_KRYLOV_FGMRES;
+      else if (!strcmp (e, "bicgstab")) o->krylov = NKP_KRYLOV_BICGSTAB;
+      else fprintf (stderr, "(%d) ignoring unknown NKP_KRYLOV '%s'\n", iam, e);
+   }
+}
+
+int main (int argc, char *argv[])
+{
+   dbg_lvl = 0;
+   nprow = npcol = 4;          // the reference's default process grid (solve_ABglobal.c:296)
+   {
+      const char *r = getenv ("RANK");
+      int v;
+      iam = (r && !parse_to_int ((char *) r, &v)) ? v : 0;
+   }
+   if (parse_cmd_line (argc, argv))
+      exit (EXIT_FAILURE);
+   if (iam != 0) {
+      // single-process build: extra ranks idle like ranks >= nprow*npcol do in the reference (:304)
+      exit (EXIT_SUCCESS);
+   }
+   if (dbg_lvl) {
+      printf ("(%d) dbg_lvl            = %d\n", iam, dbg_lvl);
+      printf ("(%d) nprow              = %ld\n", iam, nprow);
+      printf ("(%d) npcol              = %ld\n", iam, npcol);
+      printf ("(%d) vars               = %s\n", iam, vars);
+      printf ("(%d) matrix_fname       = %s\n", iam, matrix_fname);
+      printf ("(%d) inout_fname        = %s\n\n", iam, inout_fname);
+   }
+
+   if (get_sparse_matrix (matrix_fname))
+      exit (EXIT_FAILURE);
+   if (dbg_lvl)
+      printf ("(%d) row-oriented matrix read in\n", iam);
+   // index maps before setup: the water-column boundaries come from them
+   if (get_ind_maps (matrix_fname))
+      exit (EXIT_FAILURE);
+   if (coupled_tracer_cnt < 1 || (long long) coupled_tracer_cnt * tracer_state_len != flat_len) {
+      fprintf (stderr, "(%d) coupled_tracer_cnt * tracer_state_len = %d * %d does not match flat_len = %d\n", iam, coupled_tracer_cnt,
+               tracer_state_len, flat_len);
+      exit (EXIT_FAILURE);
+   }
+   int nblk = 0;
+   int_t *blk_start = nkp_column_blocks (&nblk);
+   if (blk_start == NULL) {
+      fprintf (stderr, "(%d) malloc failed in %s for blk_start\n", iam, argv[0]);
+      exit (EXIT_FAILURE);
+   }
+
+   nkp_options opt;
+   nkp_default_options (&opt);
+   opt.verbose = dbg_lvl;
+   opt.rank = iam;
+   options_from_env (&opt);
+
+   // setup = the reference's factor-only call
+   nkp_solver *solver = NULL;
+   printf ("(%d) calling %s\n", iam, prog_solver);
+   fflush (stdout);
+#ifdef NKP_DIST
+   int info = nkp_create_dist (&solver, &opt, flat_len, 0, flat_len, nnz, rowptr, colind, nzval_row_wise, blk_start, nblk,
+                               coupled_tracer_cnt, 0, 1, NULL);
+#else
+   int info = nkp_create (&solver, &opt, flat_len, nnz, rowptr, colind, nzval_row_wise, blk_start, nblk, coupled_tracer_cnt);
+#endif
+   if (dbg_lvl)
+      printf ("(%d) %s info = %d\n", iam, prog_solver, info);
+   if (info) {
+      fprintf (stderr, "(%d) %s failed: %s\n", iam, prog_solver, nkp_last_error ());
+      exit (EXIT_FAILURE);
+   }
+   free_sparse_matrix ();      // the device holds its own copy
+   free (blk_start);
+
+   char **vars_per_solve = (char **) malloc ((size_t) coupled_tracer_cnt * sizeof (char *));
+   double *B = (double *) malloc ((size_t) (flat_len ? flat_len : 1) * sizeof (double));
+   if (vars_per_solve == NULL || B == NULL) {
+      fprintf (stderr, "(%d) malloc failed in %s for vars_per_solve / B\n", iam, argv[0]);
+      exit (EXIT_FAILURE);
+   }
+
+   // each group of coupled_tracer_cnt consecutive names is one right-hand side
+   // (reference src/solve_ABglobal.c:370-409)
+   const char *varsep = ",";
+   for (char *var = strtok (vars, varsep); var; var = strtok (NULL, varsep)) {
+      for (int t = 0; t < coupled_tracer_cnt; t++) {
+         if (t > 0 && (var = strtok (NULL, varsep)) == NULL) {
+            fprintf (stderr, "(%d) error extracting tracer_ind=%d, ran out of var names\n", iam, t);
+            exit (EXIT_FAILURE);
+         }
+         if (dbg_lvl)
+            printf ("(%d) processing variable %s\n", iam, var);
+         if ((vars_per_solve[t] = strdup (var)) == NULL) {
+            fprintf (stderr, "(%d) malloc failed in %s for vars_per_solve[%d]\n", iam, argv[0], t);
+            exit (EXIT_FAILURE);
+         }
+      }
+      if (get_B_global (vars_per_solve, B))
+         exit (EXIT_FAILURE);
+
+      double berr = 0.0, relres = 0.0;
+      int iters = 0;
+      printf ("(%d) calling nkp_solve\n", iam);
+      fflush (stdout);
+      info = nkp_solve (solver, B, 1, flat_len, &berr, &iters, &relres);
+      if (dbg_lvl)
+         printf ("(%d) nkp_solve info = %d, iterations = %d, relres = %.3e, berr = %.3e\n", iam, info, iters, relres, berr);
+      if (info) {
+         fprintf (stderr, "(%d) nkp_solve failed (info = %d): %s\n(%d) %s left untouched in %s\n", iam, info, nkp_last_error (), iam,
+                  vars_per_solve[0], inout_fname);
+         exit (EXIT_FAILURE);
+      }
+      if (put_B_global (vars_per_solve, B))
+         exit (EXIT_FAILURE);
+      for (int t = 0; t < coupled_tracer_cnt; t++)
+         free (vars_per_solve[t]);
+   }
+
+   nkp_destroy (solver);
+   free_ind_maps ();
+   free (vars_per_solve);
+   free (vars);
+   free (B);
+   exit (EXIT_SUCCESS);
+}

@@ -1,0 +1,309 @@
+// Vector kernels of the Krylov drivers (gfx950).  All are HBM-bound streams: 16-byte loads
+// per lane, grid-stride, 64-lane __shfl_down wave reductions, and a FIXED number of partial
+// sums that a second tiny kernel adds in a fixed order -- so every inner product is bitwise
+// reproducible (no float atomics) and, in the multi-GPU build, is the local contribution fed
+// to one RCCL allreduce per Gram-Schmidt sweep.
+//
+// Stand in for the norm / update bookkeeping of pdgsrfs_ABXglobal (reference
+// src/SuperLU_brief_tree.txt:20).  The fused multi-dot reads w once per chunk of 8 basis
+// vectors and every basis vector exactly once.
+#include "nkp_dev.h"
+
+#define B1_THREADS 256
+
+__device__ __forceinline__ double wave_sum (double v)
+{
+#pragma unroll
+   for (int off = NKP_WAVE / 2; off > 0; off >>= 1) v += __shfl_down (v, off);
+   return v;
+}
+
+// block-wide sum, result valid in thread 0
+__device__ __forceinline__ double block_sum (double v, double *sh /* [B1_THREADS/64] */)
+{
+   v = wave_sum (v);
+   const int lane = threadIdx.x & (NKP_WAVE - 1), wv = threadIdx.x / NKP_WAVE;
+   __syncthreads ();
+   if (lane == 0) sh[wv] = v;
+   __syncthreads ();
+   double s = 0.0;
+   if (threadIdx.x == 0) {
+#pragma unroll
+      for (int w = 0; w < B1_THREADS / NKP_WAVE; w++) s += sh[w];
+   }
+   return s;
+}
+
+static inline int red_grid (int64_t n)
+{
+   int64_t g = (n + 2 * B1_THREADS - 1) / (2 * B1_THREADS);
+   if (g < 1) g = 1;
+   if (g > NKP_RED_BLOCKS) g = NKP_RED_BLOCKS;
+   return (int) g;
+}
+
+// ---------------------------------------------------------------- multi-dot
+// grid (nblk, nchunk).  partial[(chunk*nblk + blk)*(CHUNK+1) + c]; slot CHUNK of chunk 0 = w.w
+__global__ __launch_bounds__ (B1_THREADS)
+void multi_dot_kernel (const double *__restrict__ V, int64_t ld, int k, const double *__restrict__ w,
+                       int64_t n, double *__restrict__ partial)
+{
+   __shared__ double sh[B1_THREADS / NKP_WAVE];
+   const int chunk = blockIdx.y;
+   const int j0 = chunk * NKP_DOT_CHUNK;
+   const int kc = (k - j0) < NKP_DOT_CHUNK ? (k - j0) : NKP_DOT_CHUNK;
+   const double *Vc = V + (int64_t) j0 * ld;
+   double acc[NKP_DOT_CHUNK];
+#pragma unroll
+   for (int c = 0; c < NKP_DOT_CHUNK; c++) acc[c] = 0.0;
+   double accw = 0.0;
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS * 2;
+   for (int64_t i = ((int64_t) blockIdx.x * B1_THREADS + threadIdx.x) * 2; i < n; i += stride) {
+      if (i + 1 < n) {
+         const double2 w2 = *reinterpret_cast<const double2 *> (w + i);
+         accw += w2.x * w2.x + w2.y * w2.y;
+#pragma unroll
+         for (int c = 0; c < NKP_DOT_CHUNK; c++)
+            if (c < kc) {
+               const double2 v2 = *reinterpret_cast<const double2 *> (Vc + (int64_t) c * ld + i);
+               acc[c] += v2.x * w2.x + v2.y * w2.y;
+            }
+      } else {
+         const double w1 = w[i];
+         accw += w1 * w1;
+#pragma unroll
+         for (int c = 0; c < NKP_DOT_CHUNK; c++)
+            if (c < kc) acc[c] += Vc[(int64_t) c * ld + i] * w1;
+      }
+   }
+   double *out = partial + ((int64_t) chunk * gridDim.x + blockIdx.x) * (NKP_DOT_CHUNK + 1);
+#pragma unroll
+   for (int c = 0; c < NKP_DOT_CHUNK; c++) {
+      const double s = block_sum (acc[c], sh);
+      if (threadIdx.x == 0) out[c] = s;
+   }
+   const double sw = block_sum (accw, sh);
+   if (threadIdx.x == 0) out[NKP_DOT_CHUNK] = sw;
+}
+
+// one wave per output: out[j] = sum_blk partial[...], fixed order.  out[k] = w.w (chunk 0)
+__global__ __launch_bounds__ (NKP_WAVE)
+void multi_dot_finish_kernel (const double *__restrict__ partial, int nblk, int k, double *__restrict__ out)
+{
+   const int j = blockIdx.x;                   // 0..k  (k = the w.w slot)
+   const int chunk = (j < k) ? j / NKP_DOT_CHUNK : 0;
+   const int c = (j < k) ? j % NKP_DOT_CHUNK : NKP_DOT_CHUNK;
+   const double *p = partial + (int64_t) chunk * nblk * (NKP_DOT_CHUNK + 1) + c;
+   double s = 0.0;
+   for (int b = threadIdx.x; b < nblk; b += NKP_WAVE) s += p[(int64_t) b * (NKP_DOT_CHUNK + 1)];
+   s = wave_sum (s);
+   if (threadIdx.x == 0) out[j] = s;
+}
+
+void launch_multi_dot (const double *V, int64_t ld, int k, const double *w, int64_t n, double *partial, double *out, hipStream_t st)
+{
+   const int g = red_grid (n);
+   const int nchunk = k > 0 ? (k + NKP_DOT_CHUNK - 1) / NKP_DOT_CHUNK : 1;
+   hipLaunchKernelGGL (multi_dot_kernel, dim3 (g, nchunk), dim3 (B1_THREADS), 0, st, V, ld, k, w, n, partial);
+   hipLaunchKernelGGL (multi_dot_finish_kernel, dim3 (k + 1), dim3 (NKP_WAVE), 0, st, partial, g, k, out);
+}
+
+// ---------------------------------------------------------------- w -= V h, with ||w||^2
+#define B1_MAX_K NKP_MAX_K
+__global__ __launch_bounds__ (B1_THREADS)
+void update_w_kernel (const double *__restrict__ V, int64_t ld, int k, const double *__restrict__ h,
+                      double *__restrict__ w, int64_t n, double *__restrict__ partial, double sign)
+{
+   __shared__ double hs[B1_MAX_K];
+   __shared__ double sh[B1_THREADS / NKP_WAVE];
+   for (int j = threadIdx.x; j < k; j += B1_THREADS) hs[j] = sign * h[j];
+   __syncthreads ();
+   double nrm = 0.0;
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS * 2;
+   for (int64_t i = ((int64_t) blockIdx.x * B1_THREADS + threadIdx.x) * 2; i < n; i += stride) {
+      if (i + 1 < n) {
+         double2 a = *reinterpret_cast<const double2 *> (w + i);
+         int j = 0;
+         for (; j + 4 <= k; j += 4) {
+            const double2 v0 = *reinterpret_cast<const double2 *> (V + (int64_t) (j + 0) * ld + i);
+            const double2 v1 = *reinterpret_cast<const double2 *> (V + (int64_t) (j + 1) * ld + i);
+            const double2 v2 = *reinterpret_cast<const double2 *> (V + (int64_t) (j + 2) * ld + i);
+            const double2 v3 = *reinterpret_cast<const double2 *> (V + (int64_t) (j + 3) * ld + i);
+            a.x += hs[j] * v0.x; a.y += hs[j] * v0.y;
+            a.x += hs[j + 1] * v1.x; a.y += hs[j + 1] * v1.y;
+            a.x += hs[j + 2] * v2.x; a.y += hs[j + 2] * v2.y;
+            a.x += hs[j + 3] * v3.x; a.y += hs[j + 3] * v3.y;
+         }
+         for (; j < k; j++) {
+            const double2 v0 = *reinterpret_cast<const double2 *> (V + (int64_t) j * ld + i);
+            a.x += hs[j] * v0.x; a.y += hs[j] * v0.y;
+         }
+         *reinterpret_cast<double2 *> (w + i) = a;
+         nrm += a.x * a.x + a.y * a.y;
+      } else {
+         double a = w[i];
+         for (int j = 0; j < k; j++) a += hs[j] * V[(int64_t) j * ld + i];
+         w[i] = a;
+         nrm += a * a;
+      }
+   }
+   if (partial) {
+      const double s = block_sum (nrm, sh);
+      if (threadIdx.x == 0) partial[blockIdx.x] = s;
+   }
+}
+
+__global__ __launch_bounds__ (NKP_WAVE)
+void sum_partials_kernel (const double *__restrict__ partial, int nblk, double *__restrict__ out)
+{
+   double s = 0.0;
+   for (int b = threadIdx.x; b < nblk; b += NKP_WAVE) s += partial[b];
+   s = wave_sum (s);
+   if (threadIdx.x == 0) out[0] = s;
+}
+
+void launch_update_w (const double *V, int64_t ld, int k, const double *h, double *w, int64_t n, double *partial, double *out_nrm2, hipStream_t st)
+{
+   const int g = red_grid (n);
+   hipLaunchKernelGGL (update_w_kernel, dim3 (g), dim3 (B1_THREADS), 0, st, V, ld, k, h, w, n, partial, -1.0);
+   hipLaunchKernelGGL (sum_partials_kernel, dim3 (1), dim3 (NKP_WAVE), 0, st, partial, g, out_nrm2);
+}
+
+void launch_axpy_multi (const double *Z, int64_t ld, int k, const double *c, double *x, int64_t n, hipStream_t st)
+{
+   const int g = red_grid (n);
+   hipLaunchKernelGGL (update_w_kernel, dim3 (g), dim3 (B1_THREADS), 0, st, Z, ld, k, c, x, n, (double *) nullptr, 1.0);
+}
+
+// ---------------------------------------------------------------- simple streams
+__global__ __launch_bounds__ (B1_THREADS)
+void scale_to_kernel (const double *__restrict__ x, const double *__restrict__ alpha, double *__restrict__ y, int64_t n)
+{
+   const double a = alpha[0];
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS * 2;
+   for (int64_t i = ((int64_t) blockIdx.x * B1_THREADS + threadIdx.x) * 2; i < n; i += stride) {
+      if (i + 1 < n) {
+         double2 v = *reinterpret_cast<const double2 *> (x + i);
+         v.x *= a; v.y *= a;
+         *reinterpret_cast<double2 *> (y + i) = v;
+      } else
+         y[i] = a * x[i];
+   }
+}
+
+void launch_scale_to (const double *x, const double *alpha_dev, double *y, int64_t n, hipStream_t st)
+{
+   hipLaunchKernelGGL (scale_to_kernel, dim3 (red_grid (n)), dim3 (B1_THREADS), 0, st, x, alpha_dev, y, n);
+}
+
+__global__ __launch_bounds__ (B1_THREADS)
+void axpby_kernel (double a, const double *__restrict__ x, double b, double *__restrict__ y, int64_t n)
+{
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS;
+   for (int64_t i = (int64_t) blockIdx.x * B1_THREADS + threadIdx.x; i < n; i += stride)
+      y[i] = (b == 0.0 ? 0.0 : b * y[i]) + (x ? a * x[i] : a);
+}
+
+void launch_axpby (double a, const double *x, double b, double *y, int64_t n, hipStream_t st)
+{
+   hipLaunchKernelGGL (axpby_kernel, dim3 (red_grid (n) * 2), dim3 (B1_THREADS), 0, st, a, x, b, y, n);
+}
+
+void launch_copy (const double *x, double *y, int64_t n, hipStream_t st)
+{
+   (void) hipMemcpyAsync (y, x, (size_t) n * sizeof (double), hipMemcpyDeviceToDevice, st);
+}
+
+void launch_fill (double *y, double v, int64_t n, hipStream_t st)
+{
+   if (v == 0.0) (void) hipMemsetAsync (y, 0, (size_t) n * sizeof (double), st);
+   else launch_axpby (v, nullptr, 0.0, y, n, st);
+}
+
+// ---------------------------------------------------------------- dot, berr
+__global__ __launch_bounds__ (B1_THREADS)
+void dot_kernel (const double *__restrict__ x, const double *__restrict__ y, int64_t n, double *__restrict__ partial)
+{
+   __shared__ double sh[B1_THREADS / NKP_WAVE];
+   double acc = 0.0;
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS * 2;
+   for (int64_t i = ((int64_t) blockIdx.x * B1_THREADS + threadIdx.x) * 2; i < n; i += stride) {
+      if (i + 1 < n) {
+         const double2 a = *reinterpret_cast<const double2 *> (x + i);
+         const double2 b = *reinterpret_cast<const double2 *> (y + i);
+         acc += a.x * b.x + a.y * b.y;
+      } else
+         acc += x[i] * y[i];
+   }
+   const double s = block_sum (acc, sh);
+   if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+void launch_dot (const double *x, const double *y, int64_t n, double *partial, double *out, hipStream_t st)
+{
+   const int g = red_grid (n);
+   hipLaunchKernelGGL (dot_kernel, dim3 (g), dim3 (B1_THREADS), 0, st, x, y, n, partial);
+   hipLaunchKernelGGL (sum_partials_kernel, dim3 (1), dim3 (NKP_WAVE), 0, st, partial, g, out);
+}
+
+__global__ __launch_bounds__ (B1_THREADS)
+void berr_kernel (const double *__restrict__ r, const double *__restrict__ den, int64_t n, double *__restrict__ partial)
+{
+   __shared__ double sh[B1_THREADS / NKP_WAVE];
+   double m = 0.0;
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS;
+   for (int64_t i = (int64_t) blockIdx.x * B1_THREADS + threadIdx.x; i < n; i += stride) {
+      const double a = fabs (r[i]), d = den[i];
+      const double q = (d > 0.0) ? a / d : (a > 0.0 ? 1.0e300 : 0.0);
+      m = q > m ? q : m;
+   }
+   for (int off = NKP_WAVE / 2; off > 0; off >>= 1) {
+      const double o = __shfl_down (m, off);
+      m = o > m ? o : m;
+   }
+   const int lane = threadIdx.x & (NKP_WAVE - 1), wv = threadIdx.x / NKP_WAVE;
+   if (lane == 0) sh[wv] = m;
+   __syncthreads ();
+   if (threadIdx.x == 0) {
+      for (int w = 1; w < B1_THREADS / NKP_WAVE; w++) m = sh[w] > m ? sh[w] : m;
+      partial[blockIdx.x] = m;
+   }
+}
+
+__global__ __launch_bounds__ (NKP_WAVE)
+void max_partials_kernel (const double *__restrict__ partial, int nblk, double *__restrict__ out)
+{
+   double m = 0.0;
+   for (int b = threadIdx.x; b < nblk; b += NKP_WAVE) m = partial[b] > m ? partial[b] : m;
+   for (int off = NKP_WAVE / 2; off > 0; off >>= 1) {
+      const double o = __shfl_down (m, off);
+      m = o > m ? o : m;
+   }
+   if (threadIdx.x == 0) out[0] = m;
+}
+
+void launch_berr (const double *r, const double *den, int64_t n, double *partial, double *out, hipStream_t st)
+{
+   const int g = red_grid (n);
+   hipLaunchKernelGGL (berr_kernel, dim3 (g), dim3 (B1_THREADS), 0, st, r, den, n, partial);
+   hipLaunchKernelGGL (max_partials_kernel, dim3 (1), dim3 (NKP_WAVE), 0, st, partial, g, out);
+}
+
+// ---------------------------------------------------------------- Hessenberg column epilogue
+__global__ __launch_bounds__ (NKP_WAVE)
+void finish_column_kernel (double *__restrict__ h, const double *__restrict__ h2, int k,
+                           const double *__restrict__ nrm2, double *__restrict__ inv)
+{
+   if (h2)
+      for (int j = threadIdx.x; j < k; j += NKP_WAVE) h[j] += h2[j];
+   if (threadIdx.x == 0) {
+      const double t = sqrt (nrm2[0]);
+      h[k] = t;
+      inv[0] = (t > 0.0) ? 1.0 / t : 0.0;
+   }
+}
+
+void launch_finish_column (double *h, const double *h2, int k, const double *nrm2, double *inv, hipStream_t st)
+{
+   hipLaunchKernelGGL (finish_column_kernel, dim3 (1), dim3 (NKP_WAVE), 0, st, h, h2, k, nrm2, inv);
+}

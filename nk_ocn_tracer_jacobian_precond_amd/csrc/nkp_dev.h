@@ -1,0 +1,72 @@
+// Internal device-side interfaces of libnkp_hip (gfx950 only).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NKP_WAVE 64
+#define NKP_MAX_K 512           // most basis vectors a fused update kernel takes (LDS coefficients)
+
+// ---------------------------------------------------------------- CSR matrix on the device
+struct CsrDev {
+   int64_t n = 0, nnz = 0;
+   int *rowptr = nullptr;      // [n+1]
+   int *colind = nullptr;      // [nnz]
+   double *val = nullptr;      // [nnz]
+   // CSR-stream row blocks: block b owns rows [rowblk[b], rowblk[b+1]) whose entries fit the
+   // LDS staging buffer (or a single long row)
+   int *rowblk = nullptr;      // [nrowblk+1]
+   int nrowblk = 0;
+};
+
+// y = A x (mode 0) or y = b - A x (mode 1)
+void launch_csr_spmv (const CsrDev &A, const double *x, double *y, const double *b, int mode, hipStream_t st);
+// y = |A| |x| + |b|   (denominator of the componentwise backward error)
+void launch_csr_abs_spmv (const CsrDev &A, const double *x, const double *b, double *y, hipStream_t st);
+// host helper: greedy row-block partition (host arrays)
+void build_rowblocks_host (int64_t n, const int *rowptr, int **rowblk_out, int *nrowblk_out);
+
+// ---------------------------------------------------------------- water-column blocks
+// Banded LU (no pivoting) of every diagonal block, half-bandwidth P in {1,2,4}; SoA by
+// diagonal: fac[(d+P)*n + row] holds, for d<0 the L multiplier l(row,row+d), for d=0 the
+// RECIPROCAL of the U diagonal, for d>0 u(row,row+d).
+struct ColBlocksDev {
+   int64_t n = 0;
+   int nblk = 0;
+   int *blk_start = nullptr;   // [nblk+1]
+   int P = 0;                  // half bandwidth actually stored
+   int max_len = 0;            // longest block
+   int dropped = 0;            // 1 if in-block entries beyond the band were dropped
+   double *fac = nullptr;      // [(2P+1)*n]
+};
+
+// max over blocks of the in-block half bandwidth and of the block length (device reduction)
+void launch_colblock_measure (const CsrDev &A, const ColBlocksDev &B, int *d_out2 /* [bw, zero_diag_rows] */, hipStream_t st);
+// extract + factor; *d_status receives the first row with a (near-)zero pivot + 1, else 0
+void launch_colblock_factor (const CsrDev &A, ColBlocksDev &B, int *d_status, hipStream_t st);
+// z = M^-1 r
+void launch_colblock_apply (const ColBlocksDev &B, const double *r, double *z, hipStream_t st);
+
+// ---------------------------------------------------------------- BLAS-1 style kernels
+#define NKP_RED_BLOCKS 1024        // partial sums per reduction (fixed => deterministic)
+#define NKP_DOT_CHUNK 8
+
+// partial[(chunk*NKP_RED_BLOCKS + blk)*8 + c] ; then finish sums over blk in fixed order
+// out[j] = sum_i V[j*ld+i] * w[i]  j<k ;  out[k] = sum_i w[i]^2
+void launch_multi_dot (const double *V, int64_t ld, int k, const double *w, int64_t n, double *partial, double *out, hipStream_t st);
+// w -= sum_j h[j] V_j (j<k);  out_nrm2[0] = ||w_new||^2 (via partial, deterministic)
+void launch_update_w (const double *V, int64_t ld, int k, const double *h, double *w, int64_t n, double *partial, double *out_nrm2, hipStream_t st);
+// y = alpha[0] * x   (alpha on device)
+void launch_scale_to (const double *x, const double *alpha_dev, double *y, int64_t n, hipStream_t st);
+// x += sum_j c[j] Z_j (j<k)   (c on device)
+void launch_axpy_multi (const double *Z, int64_t ld, int k, const double *c, double *x, int64_t n, hipStream_t st);
+// out[0] = sum x_i*y_i
+void launch_dot (const double *x, const double *y, int64_t n, double *partial, double *out, hipStream_t st);
+// out[0] = max_i |r_i| / den_i  (den_i == 0 -> ignored when r_i == 0)
+void launch_berr (const double *r, const double *den, int64_t n, double *partial, double *out, hipStream_t st);
+// small device-side scalar programs of the Krylov drivers
+// h[j] += h2[j] (j<k); h[k] = sqrt(nrm2); inv[0] = 1/h[k] (0 if h[k]==0)
+void launch_finish_column (double *h, const double *h2, int k, const double *nrm2, double *inv, hipStream_t st);
+// y = a*x + b*y style helpers for BiCGStab
+void launch_axpby (double a, const double *x, double b, double *y, int64_t n, hipStream_t st);
+void launch_copy (const double *x, double *y, int64_t n, hipStream_t st);
+void launch_fill (double *y, double v, int64_t n, hipStream_t st);

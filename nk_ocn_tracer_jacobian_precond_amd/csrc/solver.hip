@@ -1,0 +1,661 @@
+// libnkp_hip: C ABI (include/nkp.h) + host-orchestrated, device-resident Krylov drivers.
+//
+// Replaces the pdgssvx_ABglobal / pdgssvx calls of the reference (src/solve_ABglobal.c:353,395;
+// src/solve_ABdist.c:518,571): setup once (nkp_create), then one solve per right-hand side
+// with B overwritten by X.  All vectors live in HBM for the whole solve; the host only sees
+// one Hessenberg column (<= m+2 doubles) per iteration for the Givens recurrences.
+//
+// There is NO CPU fallback in this library: every entry point that computes needs a gfx950
+// device and fails with NKP_EDEVICE otherwise.
+#include "../../include/nkp.h"
+#include "nkp_dev.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+
+static int fail (int code, const char *fmt, ...)
+{
+   char buf[512];
+   va_list ap;
+   va_start (ap, fmt);
+   vsnprintf (buf, sizeof buf, fmt, ap);
+   va_end (ap);
+   g_last_error = buf;
+   return code;
+}
+
+#define HIPCHK(call)                                                                             \
+   do {                                                                                          \
+      hipError_t e_ = (call);                                                                    \
+      if (e_ != hipSuccess) return fail (NKP_EDEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString (e_), __FILE__, __LINE__); \
+   } while (0)
+
+extern "C" const char *nkp_last_error (void) { return g_last_error.c_str (); }
+
+extern "C" int nkp_device_count (void)
+{
+   int n = 0;
+   if (hipGetDeviceCount (&n) != hipSuccess) return 0;
+   return n;
+}
+
+extern "C" int nkp_default_options (nkp_options *opt)
+{
+   if (!opt) return NKP_EINVAL;
+   memset (opt, 0, sizeof *opt);
+   opt->struct_size = (int) sizeof (nkp_options);
+   opt->precond = NKP_PRECOND_COLUMN_JACOBI;
+   opt->krylov = NKP_KRYLOV_FGMRES;
+   opt->restart = 100;
+   opt->max_iters = 20000;
+   opt->rtol = 1.0e-10;
+   opt->atol = 0.0;
+   opt->device = -1;
+   opt->verbose = 0;
+   opt->rank = 0;
+   opt->reorth = 1;
+   opt->ml_levels = 0;
+   opt->ml_smooth = 1;
+   return NKP_OK;
+}
+
+// ---------------------------------------------------------------- solver object
+struct nkp_solver {
+   nkp_options opt;
+   int device = 0;
+   hipStream_t stream = nullptr;
+   bool own_stream = false;
+   CsrDev A;
+   ColBlocksDev B;
+   int64_t n = 0, ld = 0;
+   int m = 0;
+   // work vectors
+   double *V = nullptr, *Z = nullptr, *w = nullptr, *r = nullptr, *x = nullptr, *b = nullptr, *t1 = nullptr, *t2 = nullptr;
+   double *partial = nullptr;       // reduction scratch
+   double *dscal = nullptr;         // device scalars: h[m+2] | h2[m+2] | misc[16] | ycoef[m+1]
+   double *hpin = nullptr;          // pinned host mirror
+   int *dint = nullptr;             // device ints
+   size_t device_bytes = 0;
+   double *h_dev () { return dscal; }
+   double *h2_dev () { return dscal + (m + 2); }
+   double *misc_dev () { return dscal + 2 * (m + 2); }     // [0]=nrm2 [1]=inv [2]=dot out ...
+   double *y_dev () { return dscal + 2 * (m + 2) + 16; }
+};
+
+template <class T>
+static int dev_alloc (nkp_solver *s, T **p, size_t count)
+{
+   void *q = nullptr;
+   size_t bytes = (count ? count : 1) * sizeof (T);
+   hipError_t e = hipMalloc (&q, bytes);
+   if (e != hipSuccess) return fail (NKP_ENOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString (e));
+   *p = (T *) q;
+   s->device_bytes += bytes;
+   return NKP_OK;
+}
+
+static void solver_free (nkp_solver *s)
+{
+   if (!s) return;
+   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->B.blk_start, s->B.fac, s->V, s->Z, s->w, s->r,
+                    s->x, s->b, s->t1, s->t2, s->partial, s->dscal, s->dint };
+   for (void *p : ptrs)
+      if (p) (void) hipFree (p);
+   if (s->hpin) (void) hipHostFree (s->hpin);
+   if (s->own_stream && s->stream) (void) hipStreamDestroy (s->stream);
+   delete s;
+}
+
+extern "C" void nkp_destroy (nkp_solver *s) { solver_free (s); }
+
+static void msg (const nkp_solver *s, int lvl, const char *fmt, ...)
+{
+   if (s->opt.verbose < lvl) return;
+   va_list ap;
+   va_start (ap, fmt);
+   printf ("(%d) ", s->opt.rank);
+   vprintf (fmt, ap);
+   va_end (ap);
+   fflush (stdout);
+}
+
+static void apply_precond (nkp_solver *s, const double *rin, double *zout)
+{
+   if (s->opt.precond == NKP_PRECOND_NONE) launch_copy (rin, zout, s->n, s->stream);
+   else launch_colblock_apply (s->B, rin, zout, s->stream);
+}
+
+extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t n, int64_t nnz,
+                           const int32_t *rowptr, const int32_t *colind, const double *val,
+                           const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt)
+{
+   (void) coupled_tracer_cnt;
+   if (!out) return fail (NKP_EINVAL, "nkp_create: out is NULL");
+   *out = nullptr;
+   nkp_options opt;
+   if (opt_in) {
+      if (opt_in->struct_size != (int) sizeof (nkp_options)) return fail (NKP_EINVAL, "nkp_create: nkp_options.struct_size mismatch (%d != %zu)", opt_in->struct_size, sizeof (nkp_options));
+      opt = *opt_in;
+   } else
+      nkp_default_options (&opt);
+   if (n < 0 || nnz < 0 || !rowptr || (nnz > 0 && (!colind || !val))) return fail (NKP_EINVAL, "nkp_create: bad matrix arguments");
+   if (n >= 2147483647LL || nnz >= 2147483647LL) return fail (NKP_EINVAL, "nkp_create: n/nnz exceed the int32 index schema");
+   if (rowptr[0] != 0 || rowptr[n] != nnz) return fail (NKP_EINVAL, "nkp_create: rowptr[0]=%d rowptr[n]=%d inconsistent with nnz=%lld", rowptr[0], rowptr[n], (long long) nnz);
+   if (opt.restart < 1) opt.restart = 1;
+   if (opt.restart > NKP_MAX_K - 2) opt.restart = NKP_MAX_K - 2;
+   if (opt.precond != NKP_PRECOND_NONE && opt.precond != NKP_PRECOND_COLUMN_JACOBI && opt.precond != NKP_PRECOND_MULTILEVEL)
+      return fail (NKP_EINVAL, "nkp_create: unknown preconditioner %d", opt.precond);
+   // host-side validation of what the kernels will trust
+   for (int64_t r = 0; r < n; r++) {
+      if (rowptr[r + 1] < rowptr[r]) return fail (NKP_EINVAL, "nkp_create: rowptr decreases at row %lld", (long long) r);
+      for (int e = rowptr[r]; e < rowptr[r + 1]; e++)
+         if (colind[e] < 0 || colind[e] >= n) return fail (NKP_EINVAL, "nkp_create: column index %d out of range in row %lld", colind[e], (long long) r);
+   }
+   std::vector<int> blk_default;
+   if (opt.precond != NKP_PRECOND_NONE) {
+      if (!blk_start) {
+         for (int64_t r = 0; r < n; r += NKP_WAVE) blk_default.push_back ((int) r);
+         blk_default.push_back ((int) n);
+         blk_start = blk_default.data ();
+         nblk = (int64_t) blk_default.size () - 1;
+      }
+      if (nblk < 0 || blk_start[0] != 0 || blk_start[nblk] != n) return fail (NKP_EINVAL, "nkp_create: blk_start must run from 0 to n");
+      for (int64_t b = 0; b < nblk; b++) {
+         int len = blk_start[b + 1] - blk_start[b];
+         if (len <= 0) return fail (NKP_EINVAL, "nkp_create: empty or descending block %lld", (long long) b);
+         if (len > 2 * NKP_WAVE) return fail (NKP_EINVAL, "nkp_create: block %lld has %d rows; this build supports water columns of at most %d levels", (long long) b, len, 2 * NKP_WAVE);
+      }
+   }
+
+   int ndev = 0;
+   if (hipGetDeviceCount (&ndev) != hipSuccess || ndev == 0) return fail (NKP_EDEVICE, "nkp_create: no HIP device available (this library has no CPU fallback)");
+   nkp_solver *s = new nkp_solver;
+   s->opt = opt;
+   if (opt.device >= 0) {
+      if (opt.device >= ndev) { delete s; return fail (NKP_EDEVICE, "nkp_create: device %d of %d does not exist", opt.device, ndev); }
+      if (hipSetDevice (opt.device) != hipSuccess) { delete s; return fail (NKP_EDEVICE, "hipSetDevice(%d) failed", opt.device); }
+   }
+   (void) hipGetDevice (&s->device);
+   {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties (&prop, s->device) == hipSuccess && strncmp (prop.gcnArchName, "gfx950", 6) != 0)
+         msg (s, 1, "warning: device %d is %s, kernels are built and tuned for gfx950\n", s->device, prop.gcnArchName);
+   }
+   int rc = NKP_OK;
+#define TRY(x) do { rc = (x); if (rc != NKP_OK) { solver_free (s); return rc; } } while (0)
+#define TRYHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = fail (NKP_EDEVICE, "%s failed: %s", #call, hipGetErrorString (e_)); solver_free (s); return rc; } } while (0)
+   TRYHIP (hipStreamCreateWithFlags (&s->stream, hipStreamNonBlocking));
+   s->own_stream = true;
+   s->n = n;
+   s->ld = (n + 63) & ~(int64_t) 63;
+   if (s->ld == 0) s->ld = 64;
+   s->m = opt.restart;
+
+   // matrix
+   s->A.n = n;
+   s->A.nnz = nnz;
+   TRY (dev_alloc (s, &s->A.rowptr, (size_t) n + 1));
+   TRY (dev_alloc (s, &s->A.colind, (size_t) nnz));
+   TRY (dev_alloc (s, &s->A.val, (size_t) nnz));
+   TRYHIP (hipMemcpy (s->A.rowptr, rowptr, ((size_t) n + 1) * sizeof (int), hipMemcpyHostToDevice));
+   if (nnz) {
+      TRYHIP (hipMemcpy (s->A.colind, colind, (size_t) nnz * sizeof (int), hipMemcpyHostToDevice));
+      TRYHIP (hipMemcpy (s->A.val, val, (size_t) nnz * sizeof (double), hipMemcpyHostToDevice));
+   }
+   {
+      int *rb = nullptr, nrb = 0;
+      build_rowblocks_host (n, rowptr, &rb, &nrb);
+      s->A.nrowblk = nrb;
+      rc = dev_alloc (s, &s->A.rowblk, (size_t) nrb + 1);
+      if (rc == NKP_OK && hipMemcpy (s->A.rowblk, rb, ((size_t) nrb + 1) * sizeof (int), hipMemcpyHostToDevice) != hipSuccess)
+         rc = fail (NKP_EDEVICE, "copy of row blocks failed");
+      free (rb);
+      if (rc != NKP_OK) { solver_free (s); return rc; }
+   }
+
+   // work space
+   const int m = s->m;
+   TRY (dev_alloc (s, &s->V, (size_t) s->ld * (size_t) (m + 1)));
+   TRY (dev_alloc (s, &s->Z, (size_t) s->ld * (size_t) m));
+   TRY (dev_alloc (s, &s->w, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->r, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->x, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->b, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->t1, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->t2, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->partial, (size_t) ((m + 1 + NKP_DOT_CHUNK) / NKP_DOT_CHUNK + 1) * NKP_RED_BLOCKS * (NKP_DOT_CHUNK + 1)));
+   TRY (dev_alloc (s, &s->dscal, (size_t) (3 * (m + 2) + 16 + 8)));
+   TRY (dev_alloc (s, &s->dint, 8));
+   TRYHIP (hipHostMalloc ((void **) &s->hpin, (size_t) (m + 16) * sizeof (double), hipHostMallocDefault));
+   TRYHIP (hipMemset (s->dscal, 0, (size_t) (3 * (m + 2) + 16 + 8) * sizeof (double)));
+
+   // water-column blocks
+   if (opt.precond != NKP_PRECOND_NONE) {
+      s->B.n = n;
+      s->B.nblk = (int) nblk;
+      TRY (dev_alloc (s, &s->B.blk_start, (size_t) nblk + 1));
+      TRYHIP (hipMemcpy (s->B.blk_start, blk_start, ((size_t) nblk + 1) * sizeof (int), hipMemcpyHostToDevice));
+      TRYHIP (hipMemsetAsync (s->dint, 0, 8 * sizeof (int), s->stream));
+      launch_colblock_measure (s->A, s->B, s->dint, s->stream);
+      int meas[3] = { 0, 0, 0 };
+      TRYHIP (hipMemcpyAsync (meas, s->dint, sizeof meas, hipMemcpyDeviceToHost, s->stream));
+      TRYHIP (hipStreamSynchronize (s->stream));
+      if (meas[1] > 0) {
+         rc = fail (NKP_ESINGULAR, "nkp_create: %d rows have no (or a zero) diagonal entry; the column-block preconditioner needs one (the reference only reports this: src/matrix.c:3692-3727)", meas[1]);
+         solver_free (s);
+         return rc;
+      }
+      s->B.max_len = meas[2];
+      s->B.P = meas[0] <= 1 ? 1 : meas[0] <= 2 ? 2 : 4;
+      TRY (dev_alloc (s, &s->B.fac, (size_t) (2 * s->B.P + 1) * (size_t) n));
+      TRYHIP (hipMemsetAsync (s->dint, 0, 8 * sizeof (int), s->stream));
+      launch_colblock_factor (s->A, s->B, s->dint, s->stream);
+      int st2[2] = { 0, 0 };
+      TRYHIP (hipMemcpyAsync (st2, s->dint, sizeof st2, hipMemcpyDeviceToHost, s->stream));
+      TRYHIP (hipStreamSynchronize (s->stream));
+      if (st2[0] != 0) {
+         rc = fail (NKP_ESINGULAR, "nkp_create: zero pivot at row %d while factoring its water-column block", st2[0] - 1);
+         solver_free (s);
+         return rc;
+      }
+      s->B.dropped = st2[1];
+      msg (s, 1, "column blocks: %lld blocks, longest %d rows, in-block half bandwidth %d stored as %d%s\n", (long long) nblk,
+           s->B.max_len, meas[0], s->B.P, s->B.dropped ? " (entries beyond the band dropped)" : "");
+   }
+   TRYHIP (hipStreamSynchronize (s->stream));
+   TRYHIP (hipGetLastError ());
+   msg (s, 1, "nkp_create: n = %lld, nnz = %lld, %d SpMV row blocks, %.1f MB on device %d\n", (long long) n, (long long) nnz,
+        s->A.nrowblk, (double) s->device_bytes / 1.0e6, s->device);
+   *out = s;
+   return NKP_OK;
+#undef TRY
+#undef TRYHIP
+}
+
+extern "C" int nkp_set_stream (nkp_solver *s, void *hip_stream)
+{
+   if (!s) return fail (NKP_EINVAL, "nkp_set_stream: NULL solver");
+   if (s->own_stream && s->stream) { (void) hipStreamSynchronize (s->stream); (void) hipStreamDestroy (s->stream); }
+   if (hip_stream) { s->stream = (hipStream_t) hip_stream; s->own_stream = false; }
+   else { HIPCHK (hipStreamCreateWithFlags (&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+   return NKP_OK;
+}
+
+extern "C" int64_t nkp_get_int (nkp_solver *s, const char *key)
+{
+   if (!s || !key) return -1;
+   if (!strcmp (key, "n")) return s->n;
+   if (!strcmp (key, "nnz")) return s->A.nnz;
+   if (!strcmp (key, "nblk")) return s->B.nblk;
+   if (!strcmp (key, "band")) return s->B.P;
+   if (!strcmp (key, "band_dropped")) return s->B.dropped;
+   if (!strcmp (key, "levels")) return 1;
+   if (!strcmp (key, "rowblocks")) return s->A.nrowblk;
+   if (!strcmp (key, "spmv_bytes")) return 12 * s->A.nnz + 4 * (s->n + 1) + 16 * s->n;
+   if (!strcmp (key, "precond_bytes")) return s->opt.precond == NKP_PRECOND_NONE ? 16 * s->n : (int64_t) (2 * s->B.P + 1) * 8 * s->n + 16 * s->n;
+   if (!strcmp (key, "device_bytes")) return (int64_t) s->device_bytes;
+   return -1;
+}
+
+// ---------------------------------------------------------------- device-side building blocks
+static int dot_host (nkp_solver *s, const double *x, const double *y, double *out)
+{
+   launch_dot (x, y, s->n, s->partial, s->misc_dev () + 2, s->stream);
+   HIPCHK (hipMemcpyAsync (s->hpin, s->misc_dev () + 2, sizeof (double), hipMemcpyDeviceToHost, s->stream));
+   HIPCHK (hipStreamSynchronize (s->stream));
+   *out = s->hpin[0];
+   return NKP_OK;
+}
+
+// one Arnoldi step on the device: z_j = M^-1 v_j, w = A z_j, orthogonalise against V[0..j],
+// v_{j+1} = w/||w||; leaves the Hessenberg column h[0..j+1] in s->h_dev()
+static void arnoldi_step_device (nkp_solver *s, int j)
+{
+   const int64_t ld = s->ld;
+   double *vj = s->V + (int64_t) j * ld, *zj = s->Z + (int64_t) j * ld;
+   apply_precond (s, vj, zj);
+   launch_csr_spmv (s->A, zj, s->w, nullptr, 0, s->stream);
+   launch_multi_dot (s->V, ld, j + 1, s->w, s->n, s->partial, s->h_dev (), s->stream);
+   launch_update_w (s->V, ld, j + 1, s->h_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
+   if (s->opt.reorth) {
+      launch_multi_dot (s->V, ld, j + 1, s->w, s->n, s->partial, s->h2_dev (), s->stream);
+      launch_update_w (s->V, ld, j + 1, s->h2_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
+      launch_finish_column (s->h_dev (), s->h2_dev (), j + 1, s->misc_dev (), s->misc_dev () + 1, s->stream);
+   } else
+      launch_finish_column (s->h_dev (), nullptr, j + 1, s->misc_dev (), s->misc_dev () + 1, s->stream);
+   launch_scale_to (s->w, s->misc_dev () + 1, s->V + (int64_t) (j + 1) * ld, s->n, s->stream);
+}
+
+static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
+{
+   const int m = s->m;
+   const int64_t n = s->n, ld = s->ld;
+   hipStream_t st = s->stream;
+   std::vector<double> H ((size_t) (m + 1) * m, 0.0), cs (m), sn (m), g (m + 1), y (m);
+   double bnorm2 = 0.0;
+   int rc = dot_host (s, s->b, s->b, &bnorm2);
+   if (rc) return rc;
+   const double bnorm = sqrt (bnorm2);
+   int its = 0;
+   double relres = 0.0;
+   if (!(bnorm > 0.0)) {         // b == 0 -> x = 0
+      launch_fill (s->x, 0.0, n, st);
+      *iters_out = 0;
+      *relres_out = 0.0;
+      return NKP_OK;
+   }
+   const double target = fmax (s->opt.rtol * bnorm, s->opt.atol);
+   int status = NKP_NOT_CONVERGED;
+   for (;;) {
+      // true residual
+      launch_csr_spmv (s->A, s->x, s->r, s->b, 1, st);
+      double r2 = 0.0;
+      if ((rc = dot_host (s, s->r, s->r, &r2))) return rc;
+      const double beta = sqrt (r2);
+      relres = beta / bnorm;
+      msg (s, 2, "fgmres: its = %d, true relres = %.3e\n", its, relres);
+      if (!(beta == beta)) { status = NKP_BREAKDOWN; break; }
+      if (beta <= target) { status = NKP_OK; break; }
+      if (its >= s->opt.max_iters) { status = NKP_NOT_CONVERGED; break; }
+      // v0 = r / beta
+      s->hpin[0] = 1.0 / beta;
+      HIPCHK (hipMemcpyAsync (s->misc_dev () + 1, s->hpin, sizeof (double), hipMemcpyHostToDevice, st));
+      launch_scale_to (s->r, s->misc_dev () + 1, s->V, n, st);
+      HIPCHK (hipStreamSynchronize (st));      // hpin is reused below
+      g[0] = beta;
+      int j = 0;
+      for (; j < m && its < s->opt.max_iters; j++) {
+         arnoldi_step_device (s, j);
+         HIPCHK (hipMemcpyAsync (s->hpin, s->h_dev (), (size_t) (j + 2) * sizeof (double), hipMemcpyDeviceToHost, st));
+         HIPCHK (hipStreamSynchronize (st));
+         double *hc = &H[(size_t) j * (m + 1)];
+         for (int i = 0; i <= j + 1; i++) hc[i] = s->hpin[i];
+         for (int i = 0; i < j; i++) {
+            const double t = cs[i] * hc[i] + sn[i] * hc[i + 1];
+            hc[i + 1] = -sn[i] * hc[i] + cs[i] * hc[i + 1];
+            hc[i] = t;
+         }
+         const double hjj = hc[j], hj1 = hc[j + 1];
+         const double d = hypot (hjj, hj1);
+         if (!(d > 0.0) || !(d == d)) { status = NKP_BREAKDOWN; break; }     // column j is unusable: keep k = j
+         cs[j] = hjj / d;
+         sn[j] = hj1 / d;
+         hc[j] = d;
+         hc[j + 1] = 0.0;
+         g[j + 1] = -sn[j] * g[j];
+         g[j] = cs[j] * g[j];
+         its++;
+         const double est = fabs (g[j + 1]);
+         msg (s, 3, "fgmres: its = %d, est relres = %.3e\n", its, est / bnorm);
+         if (est <= target || hj1 == 0.0) { j++; break; }
+      }
+      // y = H^-1 g (upper triangular, size j), x += Z y
+      const int k = j;
+      for (int i = k - 1; i >= 0; i--) {
+         double t = g[i];
+         for (int c = i + 1; c < k; c++) t -= H[(size_t) c * (m + 1) + i] * y[c];
+         y[i] = t / H[(size_t) i * (m + 1) + i];
+      }
+      for (int i = 0; i < k; i++) s->hpin[i] = y[i];
+      HIPCHK (hipMemcpyAsync (s->y_dev (), s->hpin, (size_t) k * sizeof (double), hipMemcpyHostToDevice, st));
+      launch_axpy_multi (s->Z, ld, k, s->y_dev (), s->x, n, st);
+      HIPCHK (hipStreamSynchronize (st));
+      if (status == NKP_BREAKDOWN) {
+         // report the true residual of what we have
+         launch_csr_spmv (s->A, s->x, s->r, s->b, 1, st);
+         if ((rc = dot_host (s, s->r, s->r, &r2))) return rc;
+         relres = sqrt (r2) / bnorm;
+         if (sqrt (r2) <= target) status = NKP_OK;
+         break;
+      }
+   }
+   HIPCHK (hipGetLastError ());
+   *iters_out = its;
+   *relres_out = relres;
+   return status;
+}
+
+// right-preconditioned BiCGStab; every inner product is a deterministic two-stage reduction
+static int bicgstab (nkp_solver *s, int *iters_out, double *relres_out)
+{
+   const int64_t n = s->n, ld = s->ld;
+   hipStream_t st = s->stream;
+   if (s->m < 2) return fail (NKP_EINVAL, "bicgstab needs restart >= 2 (it borrows the Krylov basis storage)");
+   double *r = s->r, *r0 = s->V, *p = s->V + ld, *v = s->V + 2 * ld;
+   double *ph = s->Z, *sh = s->Z + ld, *t = s->t2, *sv = s->t1;
+   int rc;
+   double bnorm2, rho = 1.0, alpha = 1.0, omega = 1.0, tmp;
+   if ((rc = dot_host (s, s->b, s->b, &bnorm2))) return rc;
+   const double bnorm = sqrt (bnorm2);
+   if (!(bnorm > 0.0)) { launch_fill (s->x, 0.0, n, st); *iters_out = 0; *relres_out = 0.0; return NKP_OK; }
+   const double target = fmax (s->opt.rtol * bnorm, s->opt.atol);
+   launch_csr_spmv (s->A, s->x, r, s->b, 1, st);
+   launch_copy (r, r0, n, st);
+   launch_fill (p, 0.0, n, st);
+   launch_fill (v, 0.0, n, st);
+   int its = 0, status = NKP_NOT_CONVERGED;
+   double rn2;
+   if ((rc = dot_host (s, r, r, &rn2))) return rc;
+   double relres = sqrt (rn2) / bnorm;
+   while (its < s->opt.max_iters) {
+      if (sqrt (rn2) <= target) { status = NKP_OK; break; }
+      double rho_new;
+      if ((rc = dot_host (s, r0, r, &rho_new))) return rc;
+      if (rho_new == 0.0 || !(rho_new == rho_new)) { status = NKP_BREAKDOWN; break; }
+      const double beta = (rho_new / rho) * (alpha / omega);
+      // p = r + beta (p - omega v)
+      launch_axpby (-omega, v, 1.0, p, n, st);
+      launch_axpby (1.0, r, beta, p, n, st);
+      apply_precond (s, p, ph);
+      launch_csr_spmv (s->A, ph, v, nullptr, 0, st);
+      if ((rc = dot_host (s, r0, v, &tmp))) return rc;
+      if (tmp == 0.0 || !(tmp == tmp)) { status = NKP_BREAKDOWN; break; }
+      alpha = rho_new / tmp;
+      // s = r - alpha v
+      launch_copy (r, sv, n, st);
+      launch_axpby (-alpha, v, 1.0, sv, n, st);
+      apply_precond (s, sv, sh);
+      launch_csr_spmv (s->A, sh, t, nullptr, 0, st);
+      double ts, tt;
+      if ((rc = dot_host (s, t, sv, &ts))) return rc;
+      if ((rc = dot_host (s, t, t, &tt))) return rc;
+      if (tt == 0.0 || !(tt == tt)) { status = NKP_BREAKDOWN; break; }
+      omega = ts / tt;
+      // x += alpha ph + omega sh ; r = s - omega t
+      launch_axpby (alpha, ph, 1.0, s->x, n, st);
+      launch_axpby (omega, sh, 1.0, s->x, n, st);
+      launch_copy (sv, r, n, st);
+      launch_axpby (-omega, t, 1.0, r, n, st);
+      rho = rho_new;
+      its++;
+      if ((rc = dot_host (s, r, r, &rn2))) return rc;
+      relres = sqrt (rn2) / bnorm;
+      msg (s, 3, "bicgstab: its = %d, recurrence relres = %.3e\n", its, relres);
+      if (omega == 0.0) { status = NKP_BREAKDOWN; break; }
+   }
+   // true residual
+   launch_csr_spmv (s->A, s->x, r, s->b, 1, st);
+   if ((rc = dot_host (s, r, r, &rn2))) return rc;
+   relres = sqrt (rn2) / bnorm;
+   if (sqrt (rn2) <= target * 1.0001) status = NKP_OK;
+   else if (status == NKP_OK) status = NKP_NOT_CONVERGED;
+   HIPCHK (hipGetLastError ());
+   *iters_out = its;
+   *relres_out = relres;
+   return status;
+}
+
+// componentwise backward error of s->x for s->b, like SuperLU's berr
+static int backward_error (nkp_solver *s, double *berr)
+{
+   launch_csr_spmv (s->A, s->x, s->r, s->b, 1, s->stream);
+   launch_csr_abs_spmv (s->A, s->x, s->b, s->t1, s->stream);
+   launch_berr (s->r, s->t1, s->n, s->partial, s->misc_dev () + 3, s->stream);
+   HIPCHK (hipMemcpyAsync (s->hpin, s->misc_dev () + 3, sizeof (double), hipMemcpyDeviceToHost, s->stream));
+   HIPCHK (hipStreamSynchronize (s->stream));
+   *berr = s->hpin[0];
+   return NKP_OK;
+}
+
+static int solve_resident (nkp_solver *s, double *berr, int *iters, double *relres)
+{
+   int it = 0;
+   double rr = 0.0;
+   int status = (s->opt.krylov == NKP_KRYLOV_BICGSTAB) ? bicgstab (s, &it, &rr) : fgmres (s, &it, &rr);
+   if (status < 0) return status;
+   if (berr) {
+      int rc = backward_error (s, berr);
+      if (rc) return rc;
+   }
+   if (iters) *iters = it;
+   if (relres) *relres = rr;
+   msg (s, 1, "nkp_solve: %s after %d iterations, ||b-Ax||/||b|| = %.3e\n", status == NKP_OK ? "converged" : status == NKP_BREAKDOWN ? "breakdown" : "NOT converged", it, rr);
+   if (status != NKP_OK) fail (status, "nkp_solve: %s after %d iterations (relres %.3e, rtol %.1e)", status == NKP_BREAKDOWN ? "breakdown" : "not converged", it, rr, s->opt.rtol);
+   return status;
+}
+
+extern "C" int nkp_solve_device (nkp_solver *s, const void *d_b, void *d_x, int use_guess, double *berr, int *iters, double *relres)
+{
+   if (!s || !d_b || !d_x) return fail (NKP_EINVAL, "nkp_solve_device: NULL argument");
+   HIPCHK (hipSetDevice (s->device));
+   const size_t bytes = (size_t) s->n * sizeof (double);
+   if (use_guess) HIPCHK (hipMemcpyAsync (s->x, d_x, bytes, hipMemcpyDeviceToDevice, s->stream));
+   else HIPCHK (hipMemsetAsync (s->x, 0, bytes, s->stream));
+   HIPCHK (hipMemcpyAsync (s->b, d_b, bytes, hipMemcpyDeviceToDevice, s->stream));
+   int status = solve_resident (s, berr, iters, relres);
+   if (status < 0) return status;
+   HIPCHK (hipMemcpyAsync (d_x, s->x, bytes, hipMemcpyDeviceToDevice, s->stream));
+   HIPCHK (hipStreamSynchronize (s->stream));
+   return status;
+}
+
+extern "C" int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t ldb, double *berr, int *iters, double *relres)
+{
+   if (!s || (nrhs > 0 && !b_in_x_out)) return fail (NKP_EINVAL, "nkp_solve: NULL argument");
+   if (nrhs < 0 || (nrhs > 0 && ldb < s->n)) return fail (NKP_EINVAL, "nkp_solve: bad nrhs/ldb");
+   HIPCHK (hipSetDevice (s->device));
+   const size_t bytes = (size_t) s->n * sizeof (double);
+   int worst = NKP_OK;
+   for (int c = 0; c < nrhs; c++) {          // nrhs = 0 is the reference's factor-only call: nothing to do
+      double *col = b_in_x_out + (size_t) c * (size_t) ldb;
+      HIPCHK (hipMemcpyAsync (s->b, col, bytes, hipMemcpyHostToDevice, s->stream));
+      HIPCHK (hipMemsetAsync (s->x, 0, bytes, s->stream));
+      int status = solve_resident (s, berr ? berr + c : nullptr, iters ? iters + c : nullptr, relres ? relres + c : nullptr);
+      if (status < 0) return status;
+      HIPCHK (hipMemcpyAsync (col, s->x, bytes, hipMemcpyDeviceToHost, s->stream));
+      HIPCHK (hipStreamSynchronize (s->stream));
+      if (status > worst) worst = status;
+   }
+   return worst;
+}
+
+// ---------------------------------------------------------------- exposed pieces (parity / roofline)
+extern "C" int nkp_spmv_device (nkp_solver *s, const void *d_x, void *d_y)
+{
+   if (!s || !d_x || !d_y) return fail (NKP_EINVAL, "nkp_spmv_device: NULL argument");
+   HIPCHK (hipSetDevice (s->device));
+   launch_csr_spmv (s->A, (const double *) d_x, (double *) d_y, nullptr, 0, s->stream);
+   HIPCHK (hipStreamSynchronize (s->stream));
+   HIPCHK (hipGetLastError ());
+   return NKP_OK;
+}
+
+extern "C" int nkp_spmv (nkp_solver *s, const double *x, double *y)
+{
+   if (!s || !x || !y) return fail (NKP_EINVAL, "nkp_spmv: NULL argument");
+   HIPCHK (hipSetDevice (s->device));
+   const size_t bytes = (size_t) s->n * sizeof (double);
+   HIPCHK (hipMemcpyAsync (s->t1, x, bytes, hipMemcpyHostToDevice, s->stream));
+   launch_csr_spmv (s->A, s->t1, s->t2, nullptr, 0, s->stream);
+   HIPCHK (hipMemcpyAsync (y, s->t2, bytes, hipMemcpyDeviceToHost, s->stream));
+   HIPCHK (hipStreamSynchronize (s->stream));
+   HIPCHK (hipGetLastError ());
+   return NKP_OK;
+}
+
+extern "C" int nkp_precond_apply (nkp_solver *s, const double *r, double *z)
+{
+   if (!s || !r || !z) return fail (NKP_EINVAL, "nkp_precond_apply: NULL argument");
+   HIPCHK (hipSetDevice (s->device));
+   const size_t bytes = (size_t) s->n * sizeof (double);
+   HIPCHK (hipMemcpyAsync (s->t1, r, bytes, hipMemcpyHostToDevice, s->stream));
+   apply_precond (s, s->t1, s->t2);
+   HIPCHK (hipMemcpyAsync (z, s->t2, bytes, hipMemcpyDeviceToHost, s->stream));
+   HIPCHK (hipStreamSynchronize (s->stream));
+   HIPCHK (hipGetLastError ());
+   return NKP_OK;
+}
+
+extern "C" int nkp_multi_dot (nkp_solver *s, const double *V, int64_t ld, int k, const double *w, double *out)
+{
+   if (!s || !V || !w || !out || k < 0 || k > s->m + 1 || ld < s->n) return fail (NKP_EINVAL, "nkp_multi_dot: bad argument (k must be <= restart+1)");
+   HIPCHK (hipSetDevice (s->device));
+   for (int j = 0; j < k; j++)
+      HIPCHK (hipMemcpyAsync (s->V + (int64_t) j * s->ld, V + (int64_t) j * ld, (size_t) s->n * sizeof (double), hipMemcpyHostToDevice, s->stream));
+   HIPCHK (hipMemcpyAsync (s->w, w, (size_t) s->n * sizeof (double), hipMemcpyHostToDevice, s->stream));
+   launch_multi_dot (s->V, s->ld, k, s->w, s->n, s->partial, s->h_dev (), s->stream);
+   HIPCHK (hipMemcpyAsync (out, s->h_dev (), (size_t) (k + 1) * sizeof (double), hipMemcpyDeviceToHost, s->stream));
+   HIPCHK (hipStreamSynchronize (s->stream));
+   HIPCHK (hipGetLastError ());
+   return NKP_OK;
+}
+
+extern "C" int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, double *avg_ms)
+{
+   if (!s || !avg_ms || reps < 1) return fail (NKP_EINVAL, "nkp_time_kernel: bad argument");
+   HIPCHK (hipSetDevice (s->device));
+   hipEvent_t e0, e1;
+   HIPCHK (hipEventCreate (&e0));
+   HIPCHK (hipEventCreate (&e1));
+   // operands: whatever is in the work vectors (made finite first)
+   launch_fill (s->t1, 1.0, s->n, s->stream);
+   if (which == 2) {
+      if (arg < 0 || arg >= s->m) return fail (NKP_EINVAL, "nkp_time_kernel: restart position out of range");
+      for (int j = 0; j <= arg + 1; j++) launch_fill (s->V + (int64_t) j * s->ld, 1.0 / (1.0 + j), s->n, s->stream);
+   }
+   for (int pass = 0; pass < 2; pass++) {      // pass 0 = warm-up
+      const int cnt = pass == 0 ? (reps < 3 ? reps : 3) : reps;
+      HIPCHK (hipEventRecord (e0, s->stream));
+      for (int i = 0; i < cnt; i++) {
+         if (which == 0) launch_csr_spmv (s->A, s->t1, s->t2, nullptr, 0, s->stream);
+         else if (which == 1) apply_precond (s, s->t1, s->t2);
+         else arnoldi_step_device (s, arg);
+      }
+      HIPCHK (hipEventRecord (e1, s->stream));
+      HIPCHK (hipEventSynchronize (e1));
+      float ms = 0.f;
+      HIPCHK (hipEventElapsedTime (&ms, e0, e1));
+      *avg_ms = (double) ms / cnt;
+   }
+   (void) hipEventDestroy (e0);
+   (void) hipEventDestroy (e1);
+   HIPCHK (hipGetLastError ());
+   return NKP_OK;
+}
+
+// ---------------------------------------------------------------- distributed flavour (next milestone)
+extern "C" int nkp_comm_unique_id (void *id128)
+{
+   (void) id128;
+   return fail (NKP_ECOMM, "nkp_comm_unique_id: the RCCL path is not built into this library yet");
+}
+
+extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global, int64_t fst_row, int64_t m_loc,
+                                int64_t nnz_loc, const int32_t *rowptr_loc, const int32_t *colind_glob, const double *val,
+                                const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt, int rank, int nranks,
+                                const void *id128)
+{
+   (void) id128;
+   if (nranks == 1 && fst_row == 0 && m_loc == n_global)
+      return nkp_create (out, opt, n_global, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt);
+   (void) rank;
+   return fail (NKP_ECOMM, "nkp_create_dist: multi-rank solves are not built into this library yet");
+}

@@ -1,0 +1,61 @@
+/* NetCDF classic-format codec (CDF-1, CDF-2 = 64-bit offset, CDF-5 = 64-bit data).
+ *
+ * The reference links libnetcdf (reference src/file_io.c:3, src/Makefile:12-13); this image
+ * has none, and the hot path only ever does "open, look a variable up, read or write ALL of
+ * it, close" (reference src/file_io.c:72-93, 222-243, 272-293, 347-368).  This codec is
+ * exactly that much of the format, written from the published classic-format grammar.
+ *
+ * Error codes follow libnetcdf's numbering for the cases the reference can hit so messages
+ * printed through handle_nc_error stay recognisable.
+ */
+#ifndef NKP_NC3_CODEC_H
+#define NKP_NC3_CODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+   NC3_NOERR = 0,
+   NC3_EBADDIM = -46,     /* dimension not found      */
+   NC3_ENOTVAR = -49,     /* variable not found       */
+   NC3_ENOTNC = -51,      /* not a classic netCDF file */
+   NC3_ERANGE = -60,      /* value not representable in the target type */
+   NC3_ENOMEM = -61,
+   NC3_EHDF5 = -101,      /* netCDF-4/HDF5 container: unsupported here */
+   NC3_ENOTATT = -43,
+   NC3_EIO = -68,         /* open/seek/short read/short write */
+   NC3_EPERM = -37        /* write to a file opened read-only */
+};
+
+enum { NC3_BYTE = 1, NC3_CHAR, NC3_SHORT, NC3_INT, NC3_FLOAT, NC3_DOUBLE,
+       NC3_UBYTE, NC3_USHORT, NC3_UINT, NC3_INT64, NC3_UINT64 };
+
+typedef struct nc3_file nc3_file;
+
+/* mode: 0 = read-only (NC_NOWRITE), 1 = read-write (NC_WRITE) */
+int nc3_open (const char *path, int writable, nc3_file **out);
+int nc3_close (nc3_file *f);
+const char *nc3_strerror (int status);
+
+int nc3_inq_dimlen (nc3_file *f, const char *dimname, size_t *len);
+int nc3_inq_varid (nc3_file *f, const char *varname, int *varid);
+/* total element count of a variable (records included) and its external type */
+int nc3_inq_var (nc3_file *f, int varid, int *nc_type, int *ndims, size_t *nelems);
+int nc3_inq_var_dimlens (nc3_file *f, int varid, size_t *dimlens /* ndims entries */);
+
+/* whole-variable transfers with libnetcdf-style type conversion */
+int nc3_get_var_double (nc3_file *f, int varid, double *out);
+int nc3_get_var_int (nc3_file *f, int varid, int *out);
+int nc3_put_var_double (nc3_file *f, int varid, const double *in);
+int nc3_put_var_int (nc3_file *f, int varid, const int *in);
+/* numeric attribute of a variable (varid -1 = global), first element, as double */
+int nc3_get_att_double (nc3_file *f, int varid, const char *attname, double *val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,208 @@
+"""ctypes binding of the C ABI in include/nkp.h (libnkp_hip.so) and of the host library.
+
+This is the Python host-side mirror of the boundary the reference's executables cross when they
+call SuperLU_DIST (reference src/solve_ABglobal.c:327-424): create ("factor") once, solve per
+right-hand side with B overwritten by X, destroy.  There is no CPU fallback: if the HIP library
+is missing or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libnkp_hip.so")
+HOST_LIB_PATH = os.path.join(_HERE, "host", "libnkp_host.so")
+
+PRECOND_NONE, PRECOND_COLUMN_JACOBI, PRECOND_MULTILEVEL = 0, 1, 3
+KRYLOV_FGMRES, KRYLOV_BICGSTAB = 0, 1
+NKP_OK, NKP_NOT_CONVERGED, NKP_BREAKDOWN = 0, 1, 2
+
+# every symbol include/nkp.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "nkp_default_options", "nkp_device_count", "nkp_create", "nkp_solve", "nkp_solve_device",
+    "nkp_spmv", "nkp_spmv_device", "nkp_precond_apply", "nkp_multi_dot", "nkp_time_kernel",
+    "nkp_get_int", "nkp_set_stream", "nkp_destroy", "nkp_last_error", "nkp_comm_unique_id",
+    "nkp_create_dist",
+]
+
+
+class NkpOptions(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int), ("precond", C.c_int), ("krylov", C.c_int), ("restart", C.c_int),
+        ("max_iters", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("device", C.c_int),
+        ("verbose", C.c_int), ("rank", C.c_int), ("reorth", C.c_int), ("ml_levels", C.c_int),
+        ("ml_smooth", C.c_int), ("reserved", C.c_int * 8),
+    ]
+
+
+class NkpError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"nkp error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libnkp_hip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or HIP_LIB_PATH
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the solve path)")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    i32p, f64p, vp = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_void_p
+    lib.nkp_default_options.argtypes = [C.POINTER(NkpOptions)]
+    lib.nkp_device_count.restype = C.c_int
+    lib.nkp_create.argtypes = [C.POINTER(vp), C.POINTER(NkpOptions), C.c_int64, C.c_int64, i32p, i32p, f64p, i32p, C.c_int64, C.c_int]
+    lib.nkp_solve.argtypes = [vp, f64p, C.c_int, C.c_int64, f64p, C.POINTER(C.c_int), f64p]
+    lib.nkp_solve_device.argtypes = [vp, vp, vp, C.c_int, f64p, C.POINTER(C.c_int), f64p]
+    lib.nkp_spmv.argtypes = [vp, f64p, f64p]
+    lib.nkp_spmv_device.argtypes = [vp, vp, vp]
+    lib.nkp_precond_apply.argtypes = [vp, f64p, f64p]
+    lib.nkp_multi_dot.argtypes = [vp, f64p, C.c_int64, C.c_int, f64p, f64p]
+    lib.nkp_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f64p]
+    lib.nkp_get_int.argtypes = [vp, C.c_char_p]
+    lib.nkp_get_int.restype = C.c_int64
+    lib.nkp_set_stream.argtypes = [vp, vp]
+    lib.nkp_destroy.argtypes = [vp]
+    lib.nkp_destroy.restype = None
+    lib.nkp_last_error.restype = C.c_char_p
+    lib.nkp_comm_unique_id.argtypes = [vp]
+    lib.nkp_create_dist.argtypes = [C.POINTER(vp), C.POINTER(NkpOptions), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                    i32p, i32p, f64p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, vp]
+    if path == HIP_LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def default_options(**overrides):
+    lib = load_library()
+    o = NkpOptions()
+    lib.nkp_default_options(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise AttributeError(f"nkp_options has no field {k}")
+        setattr(o, k, v)
+    return o
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class NkpSolver:
+    """Device-resident solver for one CSR matrix (setup = the reference's factor-only call)."""
+
+    def __init__(self, rowptr, colind, val, blk_start=None, coupled_tracer_cnt=1, **options):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rowptr = np.ascontiguousarray(rowptr, np.int32)
+        colind = np.ascontiguousarray(colind, np.int32)
+        val = np.ascontiguousarray(val, np.float64)
+        self.n = int(rowptr.size - 1)
+        self.nnz = int(colind.size)
+        opt = default_options(**options)
+        self.options = opt
+        if blk_start is not None:
+            blk_start = np.ascontiguousarray(blk_start, np.int32)
+            bp, nb = _p(blk_start, C.c_int32), blk_start.size - 1
+        else:
+            bp, nb = None, 0
+        rc = self._lib.nkp_create(C.byref(self._h), C.byref(opt), self.n, self.nnz, _p(rowptr, C.c_int32),
+                                  _p(colind, C.c_int32), _p(val, C.c_double), bp, nb, coupled_tracer_cnt)
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise NkpError(rc, self._lib.nkp_last_error().decode())
+
+    def _check(self, rc, allow=(0,)):
+        if rc not in allow:
+            raise NkpError(rc, self._lib.nkp_last_error().decode())
+        return rc
+
+    def solve(self, b, raise_on_fail=True):
+        """Returns (x, info) with info = dict(status, iters, relres, berr); b is not modified."""
+        x = np.array(b, np.float64, order="C", copy=True).reshape(-1)
+        if x.size != self.n:
+            raise ValueError(f"b has {x.size} entries, expected {self.n}")
+        berr, relres, iters = C.c_double(), C.c_double(), C.c_int()
+        rc = self._lib.nkp_solve(self._h, _p(x, C.c_double), 1, self.n, C.byref(berr), C.byref(iters), C.byref(relres))
+        self._check(rc, (0,) if raise_on_fail else (0, 1, 2))
+        return x, dict(status=rc, iters=iters.value, relres=relres.value, berr=berr.value)
+
+    def solve_device(self, d_b, d_x, use_guess=False, raise_on_fail=True):
+        """d_b / d_x: integer device addresses (e.g. torch tensor .data_ptr()) of n float64."""
+        berr, relres, iters = C.c_double(), C.c_double(), C.c_int()
+        rc = self._lib.nkp_solve_device(self._h, C.c_void_p(d_b), C.c_void_p(d_x), int(use_guess), C.byref(berr),
+                                        C.byref(iters), C.byref(relres))
+        self._check(rc, (0,) if raise_on_fail else (0, 1, 2))
+        return dict(status=rc, iters=iters.value, relres=relres.value, berr=berr.value)
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.empty(self.n)
+        self._check(self._lib.nkp_spmv(self._h, _p(x, C.c_double), _p(y, C.c_double)))
+        return y
+
+    def spmv_device(self, d_x, d_y):
+        self._check(self._lib.nkp_spmv_device(self._h, C.c_void_p(d_x), C.c_void_p(d_y)))
+
+    def precond_apply(self, r):
+        r = np.ascontiguousarray(r, np.float64)
+        z = np.empty(self.n)
+        self._check(self._lib.nkp_precond_apply(self._h, _p(r, C.c_double), _p(z, C.c_double)))
+        return z
+
+    def multi_dot(self, V, w):
+        V = np.ascontiguousarray(V, np.float64)
+        w = np.ascontiguousarray(w, np.float64)
+        k = V.shape[0]
+        out = np.empty(k + 1)
+        self._check(self._lib.nkp_multi_dot(self._h, _p(V, C.c_double), V.shape[1], k, _p(w, C.c_double), _p(out, C.c_double)))
+        return out
+
+    def time_kernel(self, which, reps=20, arg=0):
+        ms = C.c_double()
+        self._check(self._lib.nkp_time_kernel(self._h, which, arg, reps, C.byref(ms)))
+        return ms.value
+
+    def get_int(self, key):
+        return int(self._lib.nkp_get_int(self._h, key.encode()))
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.nkp_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.nkp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def device_count():
+    return int(load_library().nkp_device_count())
+
+
+def column_blocks(col_start, tracer_state_len, coupled_tracer_cnt=1):
+    """blk_start for tracer-major rows (reference src/matrix.c:778-784) from one tracer's col_start."""
+    col_start = np.asarray(col_start, np.int64)
+    parts = [col_start[:-1] + t * tracer_state_len for t in range(coupled_tracer_cnt)]
+    return np.concatenate(parts + [np.array([coupled_tracer_cnt * tracer_state_len])]).astype(np.int32)

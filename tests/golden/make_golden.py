@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory.  Run in the BUILD CONTAINER only
+(needs SciPy); the fixtures it writes are committed and are all the GPU box ever sees.
+
+Why SciPy: the reference's arithmetic for this path is SuperLU_DIST 5.1.3 (reference
+src/Makefile:3; src/solve_ABglobal.c:353,395), which is neither vendored in the reference
+repository nor installed here, and the reference ships no golden vectors.  SciPy 1.15.3's
+scipy.sparse.linalg.splu is the serial SuperLU of the same library family; two steps of
+double-precision iterative refinement mimic the reference's IterRefine=SLU_DOUBLE default.
+
+Each case writes
+  <case>_matrix.nc    matrix file with the schema gen_A writes (CDF-2)
+  <case>_tracers.nc   tracer file, [z_t][nlat][nlon] doubles, netCDF fill value on land
+  <case>_gold.npz     x_<var> = SuperLU solution per variable group (flat), relres, berr,
+                      x_test / y_spmv = SpMV known answer (scipy A @ x_test)
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse.linalg as spla
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from nk_ocn_tracer_jacobian_precond_amd import synth  # noqa: E402
+
+CASES = {
+    # name: (generator kwargs, tracer variable names)
+    "tri_12x10x6": (dict(imt=12, jmt=10, km=6, adv="donor", hmix="const", seed=0), ["IAGE"]),
+    "penta_12x10x6": (dict(imt=12, jmt=10, km=6, adv="upwind3", hmix="isop", seed=0), ["IAGE", "TRACER2"]),
+    "cent_10x9x5": (dict(imt=10, jmt=9, km=5, adv="centred", hmix="const", seed=2), ["IAGE"]),
+    "pair_8x8x5": (dict(imt=8, jmt=8, km=5, adv="donor", hmix="const", coupled_tracer_cnt=2, seed=3),
+                   ["OCMIP_BGC_PO4", "OCMIP_BGC_DOP"]),
+}
+
+
+def main():
+    for name, (kw, varnames) in CASES.items():
+        p = synth.generate(**kw)
+        A = p.scipy_csr()
+        n = p.flat_len
+        synth.write_matrix_file(p, os.path.join(HERE, f"{name}_matrix.nc"))
+        fields = synth.make_tracer_fields(p, varnames, seed=1)
+        synth.write_tracer_file(p, os.path.join(HERE, f"{name}_tracers.nc"), fields)
+        lu = spla.splu(A.tocsc())
+        out = {}
+        cnt = p.coupled_tracer_cnt
+        for g in range(0, len(varnames), cnt):
+            group = varnames[g:g + cnt]
+            b = synth.flatten(p, [fields[v] for v in group])
+            x = lu.solve(b)
+            for _ in range(2):
+                x = x + lu.solve(b - A @ x)
+            r = b - A @ x
+            out["x_" + group[0]] = x
+            out["relres_" + group[0]] = np.linalg.norm(r) / np.linalg.norm(b)
+            out["berr_" + group[0]] = np.max(np.abs(r) / (abs(A) @ np.abs(x) + np.abs(b)))
+        x_test = np.random.default_rng(7).standard_normal(n)
+        out["x_test"] = x_test
+        out["y_spmv"] = A @ x_test
+        out["cond1_est"] = spla.onenormest(A) * spla.onenormest(spla.LinearOperator((n, n), matvec=lu.solve, rmatvec=lambda v: lu.solve(v, "T")))
+        np.savez(os.path.join(HERE, f"{name}_gold.npz"), **out)
+        print(name, "n", n, "nnz", p.nnz, {k: float(v) for k, v in out.items() if np.ndim(v) == 0})
+
+
+if __name__ == "__main__":
+    main()
