@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's benchmark contract for the Jacobian-preconditioner solve path.
+
+A "step" is ONE preconditioned solve A x = b to ||b-Ax||/||b|| <= 1e-10 for a fresh right-hand
+side that is already resident in HBM (the matrix and the preconditioner hierarchy were set up
+once, like the reference's factor-once / solve-per-tracer loop, src/solve_ABglobal.c:349-409).
+Workload at N=1: the 1 degree x 60 level single-tracer Jacobian BASELINE.json's metric is quoted
+on (configs[2]); synthetic, built by nk_ocn_tracer_jacobian_precond_amd.synth with the stencil
+of the reference's shipped job (upwind3 + isop + vmix + shallow sink, test/test_gen_A.csh:22-23).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--grid IxJxK] [--adv ..] [--hmix ..]
+
+Prints ONE JSON line on rank 0.  value = unknowns solved per second over the whole job.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", default="320x384x60")
+    ap.add_argument("--adv", default="upwind3")
+    ap.add_argument("--hmix", default="isop")
+    ap.add_argument("--restart", type=int, default=100)
+    ap.add_argument("--ml-smooth", type=int, default=2)
+    ap.add_argument("--rtol", type=float, default=1e-10)
+    ap.add_argument("--max-iters", type=int, default=20000)
+    ap.add_argument("--cpu-baseline-iters", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(p, blk, gpu_iters, n_iters):
+    """Bounded CPU sample with the oracle's port (TEST INFRASTRUCTURE used only as the timed CPU
+    leg): n_iters FGMRES iterations with the water-column block preconditioner on the SAME
+    matrix, all host cores (OpenMP).  No multilevel cycle on the CPU side, so the per-iteration
+    time is a lower bound; scaled by the iteration count the GPU solve needed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ora
+    b = np.random.default_rng(1).standard_normal(p.flat_len)
+    cores = ora.num_threads()
+    ora.fgmres(p.rowptr, p.colind, p.nzval, blk, b, restart=n_iters, max_iters=2, rtol=1e-30)    # page-in
+    t0 = time.perf_counter()
+    _, info = ora.fgmres(p.rowptr, p.colind, p.nzval, blk, b, restart=n_iters, max_iters=n_iters, rtol=1e-30)
+    dt = time.perf_counter() - t0
+    per_iter = dt / max(1, info["iters"])
+    est_solve = per_iter * gpu_iters
+    return dict(value=p.flat_len / est_solve, unit="unknowns/s", cores=cores, kind="port",
+                sample=f"{info['iters']} FGMRES({n_iters}) iterations (SpMV + water-column block solve + 2-pass Gram-Schmidt, "
+                       f"no multilevel cycle => lower bound per iteration) on the same matrix: {per_iter * 1e3:.1f} ms/iteration, "
+                       f"scaled to the {gpu_iters} iterations the GPU solve needed",
+                ms_per_iteration=per_iter * 1e3, est_solve_s=est_solve)
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world != 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the solve path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from nk_ocn_tracer_jacobian_precond_amd import solver, synth
+
+    imt, jmt, km = (int(t) for t in a.grid.split("x"))
+    t0 = time.perf_counter()
+    p = synth.generate(imt=imt, jmt=jmt, km=km, adv=a.adv, hmix=a.hmix, seed=0)
+    blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    s = solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, device=local_rank,
+                         precond=solver.PRECOND_MULTILEVEL, restart=a.restart, ml_smooth=a.ml_smooth, rtol=a.rtol,
+                         max_iters=a.max_iters, rank=rank)
+    t_setup = time.perf_counter() - t0
+    n = p.flat_len
+
+    # right-hand sides resident in HBM before the timed region
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    nrhs = a.warmup + a.steps
+    B = torch.randn((nrhs, n), dtype=torch.float64, device="cuda", generator=gen)
+    X = torch.zeros((nrhs, n), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    infos = []
+    for k in range(a.warmup):
+        s.solve_device(B[k].data_ptr(), X[k].data_ptr())
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.warmup, nrhs):
+        infos.append(s.solve_device(B[k].data_ptr(), X[k].data_ptr()))
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # independent check of the last solution with torch (not the kernel under test)
+    crow = torch.from_numpy(p.rowptr.astype(np.int64)).cuda()
+    ccol = torch.from_numpy(p.colind.astype(np.int64)).cuda()
+    cval = torch.from_numpy(p.nzval).cuda()
+    At = torch.sparse_csr_tensor(crow, ccol, cval, size=(n, n))
+    r = B[-1] - (At @ X[-1].unsqueeze(1)).squeeze(1)
+    relres_check = float(torch.linalg.norm(r) / torch.linalg.norm(B[-1]))
+    del At, crow, ccol, cval
+
+    # dominant-kernel roofline: the CSR SpMV, timed with HIP events on the solver's own stream
+    spmv_ms = s.time_kernel(0, reps=200)
+    spmv_bytes = s.get_int("spmv_bytes")
+    achieved = spmv_bytes / spmv_ms / 1e6          # GB/s
+    pre_ms = s.time_kernel(1, reps=50)
+    it_ms = {f"j{j}": s.time_kernel(2, reps=10, arg=j) for j in (0, a.restart // 2, a.restart - 1)}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    iters = [i["iters"] for i in infos]
+    out = {
+        "metric": "precond_solve_throughput_1deg_ocean_jacobian",
+        "value": world * a.steps * n / dt,
+        "unit": "unknowns/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{a.grid} ({'1' if imt == 320 else '?'} degree x {km} level) single-tracer ocean Jacobian, "
+                        f"adv={a.adv} hmix={a.hmix}, n={n}, nnz={p.nnz}; FGMRES({a.restart}) + multilevel water-column "
+                        f"preconditioner V({a.ml_smooth},{a.ml_smooth}), rtol={a.rtol:g}; one solve per step, rhs resident in HBM",
+            "multi_gpu": "one replica of the solve per rank (the row-partitioned RCCL path is not built yet)" if world > 1 else "single GPU",
+        },
+        "solve": {"iterations": iters, "relres": [i["relres"] for i in infos], "berr": [i["berr"] for i in infos],
+                  "relres_checked_with_torch": relres_check, "setup_s": t_setup, "generate_s": t_gen,
+                  "levels": s.get_int("levels"), "device_MB": s.get_int("device_bytes") / 1e6,
+                  "precond_apply_ms": pre_ms, "krylov_iteration_ms": it_ms},
+        "roofline": {"kernel": "csr_spmv_stream_kernel<0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms},
+    }
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(p, blk, int(round(float(np.mean(iters)))), a.cpu_baseline_iters)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

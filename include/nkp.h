@@ -76,7 +76,14 @@ typedef struct nkp_options {
    int reorth;           /* 0 = one classical Gram-Schmidt pass, 1 = two passes (default)     */
    int ml_levels;        /* multilevel: max levels (0 = automatic)                            */
    int ml_smooth;        /* multilevel: smoothing sweeps per level per half-cycle             */
-   int reserved[8];
+   int reserved[7];
+   /* multilevel, optional: grid position (i, j) of every water-column block, nblk entries each
+    * (tracer_state_ind_to_i/_j at the block's first row, reference src/matrix.c:322-329).  With
+    * them columns are aggregated 2 x 2 in (i, j) and coloured (i + j) % 2; without them
+    * (NULL) the setup falls back to pairwise matching on the column graph.  Host pointers, read
+    * during nkp_create only. */
+   const int32_t *col_i;
+   const int32_t *col_j;
 } nkp_options;
 
 int nkp_default_options (nkp_options *opt);

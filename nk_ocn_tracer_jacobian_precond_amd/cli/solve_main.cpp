@@ -220,10 +220,19 @@ int main (int argc, char *argv[])
       exit (EXIT_FAILURE);
    }
 
+   int *col_i = (int *) malloc ((size_t) (nblk ? nblk : 1) * sizeof (int));
+   int *col_j = (int *) malloc ((size_t) (nblk ? nblk : 1) * sizeof (int));
+   if (col_i == NULL || col_j == NULL || nkp_column_coords (nblk, col_i, col_j)) {
+      fprintf (stderr, "(%d) could not derive the water-column grid positions in %s\n", iam, argv[0]);
+      exit (EXIT_FAILURE);
+   }
+
    nkp_options opt;
    nkp_default_options (&opt);
    opt.verbose = dbg_lvl;
    opt.rank = iam;
+   opt.col_i = col_i;
+   opt.col_j = col_j;
    options_from_env (&opt);
 
    // setup = the reference's factor-only call
@@ -244,6 +253,8 @@ int main (int argc, char *argv[])
    }
    free_sparse_matrix ();      // the device holds its own copy
    free (blk_start);
+   free (col_i);
+   free (col_j);
 
    char **vars_per_solve = (char **) malloc ((size_t) coupled_tracer_cnt * sizeof (char *));
    double *B = (double *) malloc ((size_t) (flat_len ? flat_len : 1) * sizeof (double));

@@ -307,3 +307,78 @@ void launch_finish_column (double *h, const double *h2, int k, const double *nrm
 {
    hipLaunchKernelGGL (finish_column_kernel, dim3 (1), dim3 (NKP_WAVE), 0, st, h, h2, k, nrm2, inv);
 }
+
+// ---------------------------------------------------------------- grid transfer / permutation
+__global__ __launch_bounds__ (B1_THREADS)
+void restrict_sum_kernel (const int *__restrict__ rptr, const int *__restrict__ ridx, const double *__restrict__ fine,
+                          double *__restrict__ coarse, int64_t nc)
+{
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS;
+   for (int64_t I = (int64_t) blockIdx.x * B1_THREADS + threadIdx.x; I < nc; I += stride) {
+      double acc = 0.0;
+      for (int q = rptr[I]; q < rptr[I + 1]; q++) acc += fine[ridx[q]];
+      coarse[I] = acc;
+   }
+}
+
+void launch_restrict_sum (const int *rptr, const int *ridx, const double *fine, double *coarse, int64_t nc, hipStream_t st)
+{
+   if (nc <= 0) return;
+   hipLaunchKernelGGL (restrict_sum_kernel, dim3 (red_grid (nc) * 2), dim3 (B1_THREADS), 0, st, rptr, ridx, fine, coarse, nc);
+}
+
+__global__ __launch_bounds__ (B1_THREADS)
+void prolong_add_kernel (const int *__restrict__ cmap, const double *__restrict__ coarse, double *__restrict__ fine, int64_t nf)
+{
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS;
+   for (int64_t i = (int64_t) blockIdx.x * B1_THREADS + threadIdx.x; i < nf; i += stride) fine[i] += coarse[cmap[i]];
+}
+
+void launch_prolong_add (const int *cmap, const double *coarse, double *fine, int64_t nf, hipStream_t st)
+{
+   if (nf <= 0) return;
+   hipLaunchKernelGGL (prolong_add_kernel, dim3 (red_grid (nf) * 2), dim3 (B1_THREADS), 0, st, cmap, coarse, fine, nf);
+}
+
+__global__ __launch_bounds__ (B1_THREADS)
+void gather_kernel (const int *__restrict__ perm, const double *__restrict__ in, double *__restrict__ out, int64_t n, int scatter)
+{
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS;
+   for (int64_t i = (int64_t) blockIdx.x * B1_THREADS + threadIdx.x; i < n; i += stride) {
+      if (scatter) out[perm[i]] = in[i];
+      else out[i] = in[perm[i]];
+   }
+}
+
+void launch_gather (const int *perm, const double *in, double *out, int64_t n, hipStream_t st)
+{
+   if (n <= 0) return;
+   hipLaunchKernelGGL (gather_kernel, dim3 (red_grid (n) * 2), dim3 (B1_THREADS), 0, st, perm, in, out, n, 0);
+}
+
+void launch_scatter (const int *perm, const double *in, double *out, int64_t n, hipStream_t st)
+{
+   if (n <= 0) return;
+   hipLaunchKernelGGL (gather_kernel, dim3 (red_grid (n) * 2), dim3 (B1_THREADS), 0, st, perm, in, out, n, 1);
+}
+
+// one wave per output row; the coarsest level is at most a few thousand unknowns
+__global__ __launch_bounds__ (B1_THREADS)
+void dense_matvec_kernel (const double *__restrict__ M, const double *__restrict__ x, double *__restrict__ y, int n)
+{
+   const int row = (int) ((blockIdx.x * B1_THREADS + threadIdx.x) / NKP_WAVE);
+   const int lane = threadIdx.x & (NKP_WAVE - 1);
+   if (row >= n) return;
+   const double *m = M + (int64_t) row * n;
+   double acc = 0.0;
+   for (int c = lane; c < n; c += NKP_WAVE) acc += m[c] * x[c];
+   acc = wave_sum (acc);
+   if (lane == 0) y[row] = acc;
+}
+
+void launch_dense_matvec (const double *Minv, const double *x, double *y, int n, hipStream_t st)
+{
+   if (n <= 0) return;
+   const int waves_per_block = B1_THREADS / NKP_WAVE;
+   hipLaunchKernelGGL (dense_matvec_kernel, dim3 ((n + waves_per_block - 1) / waves_per_block), dim3 (B1_THREADS), 0, st, Minv, x, y, n);
+}

@@ -151,10 +151,10 @@ void colblock_factor_kernel (const int *__restrict__ rowptr, const int *__restri
 // ---------------------------------------------------------------- apply  z = (LU)^-1 r
 template <int P, int RPL>
 __global__ __launch_bounds__ (CB_THREADS)
-void colblock_apply_kernel (const int *__restrict__ blk_start, int nblk, int64_t n,
-                            const double *__restrict__ fac, const double *__restrict__ rhs, double *__restrict__ z)
+void colblock_apply_kernel (const int *__restrict__ blk_start, int b_first, int nblk, int64_t n,
+                            const double *__restrict__ fac, const double *__restrict__ rhs, double *__restrict__ z, int accumulate)
 {
-   const int b = wave_block_id ();
+   const int b = wave_block_id () + b_first;
    if (b >= nblk) return;
    const int lane = threadIdx.x & (NKP_WAVE - 1);
    const int r0 = blk_start[b];
@@ -216,7 +216,10 @@ void colblock_apply_kernel (const int *__restrict__ blk_start, int nblk, int64_t
 #pragma unroll
    for (int s = 0; s < RPL; s++) {
       const int li = s * NKP_WAVE + lane;
-      if (li < len) z[(int64_t) r0 + li] = y[s];
+      if (li < len) {
+         if (accumulate) z[(int64_t) r0 + li] += y[s];
+         else z[(int64_t) r0 + li] = y[s];
+      }
    }
 }
 
@@ -230,15 +233,16 @@ void launch_colblock_measure (const CsrDev &A, const ColBlocksDev &B, int *d_out
                        A.rowptr, A.colind, A.val, B.blk_start, B.nblk, d_out3);
 }
 
-#define CB_DISPATCH(KERNEL, ...)                                                                   \
+#define CB_DISPATCH(KERNEL, ...) CB_DISPATCH_N (KERNEL, B.nblk, __VA_ARGS__)
+#define CB_DISPATCH_N(KERNEL, NB, ...)                                                             \
    do {                                                                                           \
       const int rpl = B.max_len <= NKP_WAVE ? 1 : 2;                                              \
-      if (B.P == 1 && rpl == 1) hipLaunchKernelGGL ((KERNEL<1, 1>), cb_grid (B.nblk), dim3 (CB_THREADS), 0, st, __VA_ARGS__); \
-      else if (B.P == 1) hipLaunchKernelGGL ((KERNEL<1, 2>), cb_grid (B.nblk), dim3 (CB_THREADS), 0, st, __VA_ARGS__);        \
-      else if (B.P == 2 && rpl == 1) hipLaunchKernelGGL ((KERNEL<2, 1>), cb_grid (B.nblk), dim3 (CB_THREADS), 0, st, __VA_ARGS__); \
-      else if (B.P == 2) hipLaunchKernelGGL ((KERNEL<2, 2>), cb_grid (B.nblk), dim3 (CB_THREADS), 0, st, __VA_ARGS__);        \
-      else if (rpl == 1) hipLaunchKernelGGL ((KERNEL<4, 1>), cb_grid (B.nblk), dim3 (CB_THREADS), 0, st, __VA_ARGS__);        \
-      else hipLaunchKernelGGL ((KERNEL<4, 2>), cb_grid (B.nblk), dim3 (CB_THREADS), 0, st, __VA_ARGS__);                      \
+      if (B.P == 1 && rpl == 1) hipLaunchKernelGGL ((KERNEL<1, 1>), cb_grid (NB), dim3 (CB_THREADS), 0, st, __VA_ARGS__); \
+      else if (B.P == 1) hipLaunchKernelGGL ((KERNEL<1, 2>), cb_grid (NB), dim3 (CB_THREADS), 0, st, __VA_ARGS__);        \
+      else if (B.P == 2 && rpl == 1) hipLaunchKernelGGL ((KERNEL<2, 1>), cb_grid (NB), dim3 (CB_THREADS), 0, st, __VA_ARGS__); \
+      else if (B.P == 2) hipLaunchKernelGGL ((KERNEL<2, 2>), cb_grid (NB), dim3 (CB_THREADS), 0, st, __VA_ARGS__);        \
+      else if (rpl == 1) hipLaunchKernelGGL ((KERNEL<4, 1>), cb_grid (NB), dim3 (CB_THREADS), 0, st, __VA_ARGS__);        \
+      else hipLaunchKernelGGL ((KERNEL<4, 2>), cb_grid (NB), dim3 (CB_THREADS), 0, st, __VA_ARGS__);                      \
    } while (0)
 
 void launch_colblock_factor (const CsrDev &A, ColBlocksDev &B, int *d_status, hipStream_t st)
@@ -251,5 +255,11 @@ void launch_colblock_factor (const CsrDev &A, ColBlocksDev &B, int *d_status, hi
 void launch_colblock_apply (const ColBlocksDev &B, const double *r, double *z, hipStream_t st)
 {
    if (B.nblk == 0) return;
-   CB_DISPATCH (colblock_apply_kernel, B.blk_start, B.nblk, B.n, B.fac, r, z);
+   CB_DISPATCH (colblock_apply_kernel, B.blk_start, 0, B.nblk, B.n, B.fac, r, z, 0);
+}
+
+void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, hipStream_t st)
+{
+   if (b1 <= b0) return;
+   CB_DISPATCH_N (colblock_apply_kernel, b1 - b0, B.blk_start, b0, b1, B.n, B.fac, r, z, accumulate);
 }

@@ -1,0 +1,33 @@
+// Multilevel water-column preconditioner: data structures (see multilevel.hip).
+#pragma once
+#include "nkp_dev.h"
+
+#include <vector>
+
+struct MlLevel {
+   int64_t n = 0;
+   CsrDev L;                    // level operator, colour-major row order
+   ColBlocksDev B;              // factored water-column blocks of L (absent on the coarsest level)
+   int color_rb[3] = { 0, 0, 0 };    // SpMV row blocks of colour c: [color_rb[c], color_rb[c+1])
+   int color_blk[3] = { 0, 0, 0 };   // column blocks of colour c
+   int64_t nc = 0;              // rows of the next coarser level
+   int *cmap = nullptr;         // fine row -> coarse row                 (prolongation)
+   int *rptr = nullptr, *ridx = nullptr;   // coarse row -> its fine rows (restriction)
+   double *x = nullptr, *b = nullptr, *r = nullptr;
+};
+
+struct MlHierarchy {
+   std::vector<MlLevel> lev;
+   int *perm0 = nullptr;        // level-0 row i holds original row perm0[i]
+   double *coarse_inv = nullptr;   // dense inverse of the coarsest operator (row-major)
+   int nu = 1;                  // Gauss-Seidel sweeps before and after the coarse correction
+   size_t device_bytes = 0;
+};
+
+// returns 0, or a negative nkp error code with a message in err
+int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, const double *val,
+              const int *blk_start, int64_t nblk, const int *col_i, const int *col_j, int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
+              hipStream_t st, char *err, size_t errlen);
+void ml_free (MlHierarchy &H);
+// z = V-cycle(r) in the ORIGINAL row order
+void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st);

@@ -1,0 +1,577 @@
+// Multilevel water-column preconditioner (NKP_PRECOND_MULTILEVEL).
+//
+// Why it exists: with exact water-column blocks alone, restarted GMRES needs >1e4 iterations
+// on upwind3/centred Jacobians at 3 degrees and stalls outright at 1 degree (SURVEY.md section 7,
+// hard part 1) -- which is why the reference uses a sparse direct solver
+// (src/solve_ABglobal.c:353).  This preconditioner keeps the column-block kernel of colblock.hip
+// as its smoother and adds the two things the block-Jacobi sweep lacks:
+//
+//  1. a monotone low-order twin L of A: every wrong-signed coupling BETWEEN water columns is
+//     removed by symmetric artificial diffusion d_ij = max(0, -a_ij, -a_ji) (algebraic
+//     upwinding: centred / upwind3 advection weights, src/matrix.c:1239-1273, 1610-1690, become
+//     the donor-cell operator; the +-isopycnal cross terms, :881-930, become positive); entries
+//     inside a column stay exact.  -L is an M-matrix, so column-block Gauss-Seidel converges on
+//     it and on every Galerkin coarsening of it.
+//  2. a hierarchy: columns are aggregated pairwise twice (~4 columns per aggregate, levels k
+//     kept), P is piecewise constant, L_{l+1} = P^T L_l P; every level keeps the "contiguous
+//     water column" layout, so the SAME wave-per-column kernels run on all levels.  Columns are
+//     2-coloured and stored colour-major, so a Gauss-Seidel half-sweep is one row-range
+//     residual SpMV + one block-range column solve.
+//
+// One V(nu,nu) cycle approximates L^-1; FGMRES (solver.hip) iterates on the original A.
+// Setup is host code (O(nnz)); every cycle runs on the device.
+#include "nkp_dev.h"
+#include "multilevel.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <array>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+struct HostCsr {
+   int64_t n = 0;
+   std::vector<int> rowptr, colind;
+   std::vector<double> val;
+};
+
+// ---------------------------------------------------------------- low-order twin
+// L = A + D - diag(rowsum D), D_ij = max(0, -a_ij, -a_ji) for i, j in different columns
+void build_low_order (int64_t n, const int *rowptr, const int *colind, const double *val, const std::vector<int> &col_of, HostCsr &L)
+{
+   const int64_t nnz = rowptr[n];
+   // transpose (values + row ids), rows of T sorted by column because A is scanned in row order
+   std::vector<int> tptr (n + 1, 0), tcol (nnz);
+   std::vector<double> tval (nnz);
+   for (int64_t e = 0; e < nnz; e++) tptr[colind[e] + 1]++;
+   for (int64_t r = 0; r < n; r++) tptr[r + 1] += tptr[r];
+   {
+      std::vector<int> fill (tptr.begin (), tptr.end () - 1);
+      for (int64_t r = 0; r < n; r++)
+         for (int e = rowptr[r]; e < rowptr[r + 1]; e++) {
+            const int q = fill[colind[e]]++;
+            tcol[q] = (int) r;
+            tval[q] = val[e];
+         }
+   }
+   L.n = n;
+   L.rowptr.assign (n + 1, 0);
+   L.colind.clear ();
+   L.val.clear ();
+   L.colind.reserve (nnz);
+   L.val.reserve (nnz);
+   for (int64_t i = 0; i < n; i++) {
+      double dsum = 0.0;
+      int64_t diag_pos = -1;
+      int t = tptr[i];
+      const int tend = tptr[i + 1];
+      for (int e = rowptr[i]; e < rowptr[i + 1]; e++) {
+         const int j = colind[e];
+         double a = val[e];
+         if (j == i) {
+            diag_pos = (int64_t) L.colind.size ();
+            L.colind.push_back (j);
+            L.val.push_back (a);
+            continue;
+         }
+         if (col_of[j] != col_of[i]) {
+            while (t < tend && tcol[t] < j) t++;
+            const double aji = (t < tend && tcol[t] == j) ? tval[t] : 0.0;
+            double d = 0.0;
+            if (-a > d) d = -a;
+            if (-aji > d) d = -aji;
+            a += d;
+            dsum += d;
+            if (a == 0.0) continue;          // the removed (now zero) coupling is not stored
+         }
+         L.colind.push_back (j);
+         L.val.push_back (a);
+      }
+      if (diag_pos >= 0) L.val[diag_pos] -= dsum;
+      L.rowptr[i + 1] = (int) L.colind.size ();
+   }
+}
+
+// ---------------------------------------------------------------- column graph helpers
+struct ColGraph {
+   std::vector<int> ptr, nbr;
+   std::vector<double> w;
+};
+
+void build_col_graph (const HostCsr &L, const std::vector<int> &blk_start, const std::vector<int> &col_of, ColGraph &G)
+{
+   const int ncol = (int) blk_start.size () - 1;
+   G.ptr.assign (ncol + 1, 0);
+   G.nbr.clear ();
+   G.w.clear ();
+   std::vector<double> acc (ncol, 0.0);
+   std::vector<int> touched;
+   for (int c = 0; c < ncol; c++) {
+      touched.clear ();
+      for (int r = blk_start[c]; r < blk_start[c + 1]; r++)
+         for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++) {
+            const int c2 = col_of[L.colind[e]];
+            if (c2 == c) continue;
+            if (acc[c2] == 0.0) touched.push_back (c2);
+            acc[c2] += fabs (L.val[e]) + 1.0e-300;
+         }
+      std::sort (touched.begin (), touched.end ());
+      for (int c2 : touched) {
+         G.nbr.push_back (c2);
+         G.w.push_back (acc[c2]);
+         acc[c2] = 0.0;
+      }
+      G.ptr[c + 1] = (int) G.nbr.size ();
+   }
+}
+
+// one pass of pairwise matching on a weighted graph; returns group id per node (ordered by first member)
+int pairwise_match (int nn, const std::vector<int> &ptr, const std::vector<int> &nbr, const std::vector<double> &w, std::vector<int> &group)
+{
+   group.assign (nn, -1);
+   int ng = 0;
+   for (int c = 0; c < nn; c++) {
+      if (group[c] >= 0) continue;
+      int best = -1;
+      double bw = 0.0;
+      for (int q = ptr[c]; q < ptr[c + 1]; q++)
+         if (group[nbr[q]] < 0 && nbr[q] != c && w[q] > bw) { bw = w[q]; best = nbr[q]; }
+      group[c] = ng;
+      if (best >= 0) group[best] = ng;
+      ng++;
+   }
+   return ng;
+}
+
+// collapse a node graph onto groups
+void collapse_graph (int nn, int ng, const std::vector<int> &group, const ColGraph &G, ColGraph &H)
+{
+   std::vector<std::vector<int>> members (ng);
+   for (int c = 0; c < nn; c++) members[group[c]].push_back (c);
+   H.ptr.assign (ng + 1, 0);
+   H.nbr.clear ();
+   H.w.clear ();
+   std::vector<double> acc (ng, 0.0);
+   std::vector<int> touched;
+   for (int g = 0; g < ng; g++) {
+      touched.clear ();
+      for (int c : members[g])
+         for (int q = G.ptr[c]; q < G.ptr[c + 1]; q++) {
+            const int g2 = group[G.nbr[q]];
+            if (g2 == g) continue;
+            if (acc[g2] == 0.0) touched.push_back (g2);
+            acc[g2] += G.w[q];
+         }
+      std::sort (touched.begin (), touched.end ());
+      for (int g2 : touched) {
+         H.nbr.push_back (g2);
+         H.w.push_back (acc[g2]);
+         acc[g2] = 0.0;
+      }
+      H.ptr[g + 1] = (int) H.nbr.size ();
+   }
+}
+
+// greedy 2-colouring: each column takes the colour its already-coloured neighbours use least (by weight)
+void two_colour (int ncol, const ColGraph &G, std::vector<int> &colour)
+{
+   colour.assign (ncol, -1);
+   for (int c = 0; c < ncol; c++) {
+      double w0 = 0.0, w1 = 0.0;
+      for (int q = G.ptr[c]; q < G.ptr[c + 1]; q++) {
+         const int k = colour[G.nbr[q]];
+         if (k == 0) w0 += G.w[q];
+         else if (k == 1) w1 += G.w[q];
+      }
+      colour[c] = (w0 <= w1) ? 0 : 1;
+      if (w0 == 0.0 && w1 == 0.0) colour[c] = 0;
+   }
+}
+
+// Galerkin product with a piecewise-constant P given as fine row -> coarse row
+void galerkin (const HostCsr &L, const std::vector<int> &cmap, int64_t nc, HostCsr &C)
+{
+   // coarse row -> fine rows
+   std::vector<int> rptr (nc + 1, 0), ridx (L.n);
+   for (int64_t i = 0; i < L.n; i++) rptr[cmap[i] + 1]++;
+   for (int64_t I = 0; I < nc; I++) rptr[I + 1] += rptr[I];
+   {
+      std::vector<int> fill (rptr.begin (), rptr.end () - 1);
+      for (int64_t i = 0; i < L.n; i++) ridx[fill[cmap[i]]++] = (int) i;
+   }
+   C.n = nc;
+   C.rowptr.assign (nc + 1, 0);
+   C.colind.clear ();
+   C.val.clear ();
+   C.colind.reserve (L.colind.size () / 2);
+   C.val.reserve (L.colind.size () / 2);
+   std::vector<double> acc (nc, 0.0);
+   std::vector<char> mark (nc, 0);
+   std::vector<int> touched;
+   for (int64_t I = 0; I < nc; I++) {
+      touched.clear ();
+      for (int q = rptr[I]; q < rptr[I + 1]; q++) {
+         const int i = ridx[q];
+         for (int e = L.rowptr[i]; e < L.rowptr[i + 1]; e++) {
+            const int J = cmap[L.colind[e]];
+            if (!mark[J]) { mark[J] = 1; touched.push_back (J); }
+            acc[J] += L.val[e];
+         }
+      }
+      std::sort (touched.begin (), touched.end ());
+      for (int J : touched) {
+         if (acc[J] != 0.0 || J == I) {
+            C.colind.push_back (J);
+            C.val.push_back (acc[J]);
+         }
+         acc[J] = 0.0;
+         mark[J] = 0;
+      }
+      C.rowptr[I + 1] = (int) C.colind.size ();
+   }
+}
+
+// dense inverse by Gauss-Jordan with partial pivoting (coarsest level only); returns false if singular
+bool dense_inverse (int n, std::vector<double> &a /* row-major n*n, overwritten by its inverse */)
+{
+   std::vector<double> inv ((size_t) n * n, 0.0);
+   for (int i = 0; i < n; i++) inv[(size_t) i * n + i] = 1.0;
+   for (int k = 0; k < n; k++) {
+      int p = k;
+      double mx = fabs (a[(size_t) k * n + k]);
+      for (int i = k + 1; i < n; i++)
+         if (fabs (a[(size_t) i * n + k]) > mx) { mx = fabs (a[(size_t) i * n + k]); p = i; }
+      if (!(mx > 0.0)) return false;
+      if (p != k)
+         for (int c = 0; c < n; c++) {
+            std::swap (a[(size_t) k * n + c], a[(size_t) p * n + c]);
+            std::swap (inv[(size_t) k * n + c], inv[(size_t) p * n + c]);
+         }
+      const double piv = 1.0 / a[(size_t) k * n + k];
+      for (int c = 0; c < n; c++) { a[(size_t) k * n + c] *= piv; inv[(size_t) k * n + c] *= piv; }
+      for (int i = 0; i < n; i++) {
+         if (i == k) continue;
+         const double f = a[(size_t) i * n + k];
+         if (f == 0.0) continue;
+         double *ai = &a[(size_t) i * n], *ak = &a[(size_t) k * n], *ii = &inv[(size_t) i * n], *ik = &inv[(size_t) k * n];
+         for (int c = 0; c < n; c++) { ai[c] -= f * ak[c]; ii[c] -= f * ik[c]; }
+      }
+   }
+   a.swap (inv);
+   return true;
+}
+
+template <class T>
+bool upload (T **dst, const T *src, size_t count, size_t *bytes)
+{
+   void *q = nullptr;
+   const size_t b = (count ? count : 1) * sizeof (T);
+   if (hipMalloc (&q, b) != hipSuccess) return false;
+   if (count && src && hipMemcpy (q, src, count * sizeof (T), hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree (q); return false; }
+   *dst = (T *) q;
+   *bytes += b;
+   return true;
+}
+
+}  // namespace
+
+// ================================================================ setup
+int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, const double *val,
+              const int *blk_start_in, int64_t nblk, const int *col_i, const int *col_j, int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
+              hipStream_t st, char *err, size_t errlen)
+{
+#define ML_FAIL(code, ...) do { snprintf (err, errlen, __VA_ARGS__); return (code); } while (0)
+   H.nu = nu < 1 ? 1 : nu;
+   if (max_levels <= 0) max_levels = 12;
+
+   // ---- natural-order data of every level (host)
+   struct Nat {
+      HostCsr L;
+      std::vector<int> blk_start, col_of, colour, agg;   // per column: colour, aggregate id
+      std::vector<int> cmap;                            // fine row -> coarse row (natural orders)
+      std::vector<int> perm, inv;                       // perm[new] = old ; inv[old] = new  (colour-major)
+      std::vector<int> gi, gj, gt;                      // optional grid position / tracer of every column
+      int nagg = 0;
+      int ncol0 = 0;                                    // columns of colour 0
+   };
+   std::vector<Nat> nat (1);
+   {
+      Nat &N = nat[0];
+      N.blk_start.assign (blk_start_in, blk_start_in + nblk + 1);
+      N.col_of.resize (n);
+      for (int64_t c = 0; c < nblk; c++)
+         for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.col_of[r] = (int) c;
+      build_low_order (n, rowptr, colind, val, N.col_of, N.L);
+      if (col_i && col_j) {
+         N.gi.assign (col_i, col_i + nblk);
+         N.gj.assign (col_j, col_j + nblk);
+         N.gt.resize (nblk);
+         const int64_t per = (tracer_cnt > 1 && nblk % tracer_cnt == 0) ? nblk / tracer_cnt : nblk;
+         for (int64_t c = 0; c < nblk; c++) N.gt[c] = (int) (c / per);
+      }
+   }
+   for (int l = 0;; l++) {
+      Nat &N = nat[l];
+      const int ncol = (int) N.blk_start.size () - 1;
+      ColGraph G;
+      build_col_graph (N.L, N.blk_start, N.col_of, G);
+      const bool geo = !N.gi.empty ();
+      if (geo) {
+         N.colour.resize (ncol);
+         for (int c = 0; c < ncol; c++) N.colour[c] = (N.gi[c] + N.gj[c]) & 1;
+      } else
+         two_colour (ncol, G, N.colour);
+      // colour-major permutation of rows
+      N.perm.clear ();
+      N.perm.reserve (N.L.n);
+      N.ncol0 = 0;
+      for (int pass = 0; pass < 2; pass++)
+         for (int c = 0; c < ncol; c++)
+            if (N.colour[c] == pass) {
+               if (pass == 0) N.ncol0++;
+               for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.perm.push_back (r);
+            }
+      N.inv.resize (N.L.n);
+      for (int64_t i = 0; i < N.L.n; i++) N.inv[N.perm[i]] = (int) i;
+
+      const bool last = (l + 1 >= max_levels) || (N.L.n <= coarsest_rows) || ncol <= 4;
+      if (last) break;
+      int n2 = 0;
+      N.agg.resize (ncol);
+      std::vector<int> cgi, cgj, cgt;
+      if (geo) {
+         // 2 x 2 blocks of columns in (i, j), never across tracers; ids in order of first member
+         std::vector<std::pair<std::array<int, 3>, int>> keys (ncol);
+         for (int c = 0; c < ncol; c++) keys[c] = { { N.gt[c], N.gj[c] >> 1, N.gi[c] >> 1 }, c };
+         std::vector<std::pair<std::array<int, 3>, int>> sorted (keys);
+         std::sort (sorted.begin (), sorted.end ());
+         std::vector<int> gid_sorted (ncol), first_member;
+         int ng = 0;
+         for (int q = 0; q < ncol; q++) {
+            if (q == 0 || sorted[q].first != sorted[q - 1].first) { first_member.push_back (sorted[q].second); ng++; }
+            gid_sorted[sorted[q].second] = ng - 1;
+         }
+         // renumber groups by their first (lowest natural index) member so coarse columns keep the j, i order
+         std::vector<int> order (ng);
+         std::iota (order.begin (), order.end (), 0);
+         std::sort (order.begin (), order.end (), [&] (int a, int b) { return first_member[a] < first_member[b]; });
+         std::vector<int> newid (ng);
+         for (int q = 0; q < ng; q++) newid[order[q]] = q;
+         cgi.resize (ng); cgj.resize (ng); cgt.resize (ng);
+         for (int c = 0; c < ncol; c++) {
+            const int a = newid[gid_sorted[c]];
+            N.agg[c] = a;
+            cgi[a] = N.gi[c] >> 1; cgj[a] = N.gj[c] >> 1; cgt[a] = N.gt[c];
+         }
+         n2 = ng;
+      } else {
+         // two passes of pairwise matching -> aggregates of up to 4 columns
+         std::vector<int> g1, g2;
+         const int n1 = pairwise_match (ncol, G.ptr, G.nbr, G.w, g1);
+         ColGraph G1;
+         collapse_graph (ncol, n1, g1, G, G1);
+         n2 = pairwise_match (n1, G1.ptr, G1.nbr, G1.w, g2);
+         for (int c = 0; c < ncol; c++) N.agg[c] = g2[g1[c]];
+      }
+      N.nagg = n2;
+      if (n2 >= ncol) break;                            // no coarsening possible
+      // coarse columns: length = longest member
+      std::vector<int> clen (n2, 0);
+      for (int c = 0; c < ncol; c++) clen[N.agg[c]] = std::max (clen[N.agg[c]], N.blk_start[c + 1] - N.blk_start[c]);
+      Nat C;
+      C.gi.swap (cgi); C.gj.swap (cgj); C.gt.swap (cgt);
+      C.blk_start.assign (n2 + 1, 0);
+      for (int a = 0; a < n2; a++) C.blk_start[a + 1] = C.blk_start[a] + clen[a];
+      const int64_t ncr = C.blk_start[n2];
+      N.cmap.resize (N.L.n);
+      for (int c = 0; c < ncol; c++)
+         for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.cmap[r] = C.blk_start[N.agg[c]] + (r - N.blk_start[c]);
+      galerkin (N.L, N.cmap, ncr, C.L);
+      C.col_of.resize (ncr);
+      for (int a = 0; a < n2; a++)
+         for (int r = C.blk_start[a]; r < C.blk_start[a + 1]; r++) C.col_of[r] = a;
+      nat.push_back (std::move (C));
+   }
+
+   // ---- device levels in colour-major order
+   const int nlev = (int) nat.size ();
+   H.lev.resize (nlev);
+   for (int l = 0; l < nlev; l++) {
+      Nat &N = nat[l];
+      MlLevel &V = H.lev[l];
+      const int64_t nl = N.L.n;
+      const int ncol = (int) N.blk_start.size () - 1;
+      V.n = nl;
+      // permuted CSR: row new = perm[new]; columns relabelled through inv, then sorted
+      std::vector<int> prow (nl + 1, 0), pcol (N.L.colind.size ());
+      std::vector<double> pval (N.L.colind.size ());
+      std::vector<std::pair<int, double>> tmp;
+      for (int64_t i = 0; i < nl; i++) {
+         const int o = N.perm[i];
+         tmp.clear ();
+         for (int e = N.L.rowptr[o]; e < N.L.rowptr[o + 1]; e++) tmp.emplace_back (N.inv[N.L.colind[e]], N.L.val[e]);
+         std::sort (tmp.begin (), tmp.end ());
+         int q = prow[i];
+         for (auto &t : tmp) { pcol[q] = t.first; pval[q] = t.second; q++; }
+         prow[i + 1] = q;
+      }
+      // permuted column blocks
+      std::vector<int> pblk;
+      pblk.reserve (ncol + 1);
+      pblk.push_back (0);
+      for (int pass = 0; pass < 2; pass++)
+         for (int c = 0; c < ncol; c++)
+            if (N.colour[c] == pass) pblk.push_back (pblk.back () + (N.blk_start[c + 1] - N.blk_start[c]));
+      V.color_blk[0] = 0;
+      V.color_blk[1] = N.ncol0;
+      V.color_blk[2] = ncol;
+      const int rows0 = pblk[N.ncol0];
+      // row blocks per colour (must not straddle the colour boundary)
+      int *rb0 = nullptr, *rb1 = nullptr, nrb0 = 0, nrb1 = 0;
+      build_rowblocks_host (rows0, prow.data (), &rb0, &nrb0);
+      {
+         std::vector<int> shifted (nl - rows0 + 1);
+         for (int64_t i = rows0; i <= nl; i++) shifted[i - rows0] = prow[i] - prow[rows0];
+         build_rowblocks_host (nl - rows0, shifted.data (), &rb1, &nrb1);
+      }
+      std::vector<int> rb (nrb0 + nrb1 + 1);
+      for (int i = 0; i <= nrb0; i++) rb[i] = rb0[i];
+      for (int i = 1; i <= nrb1; i++) rb[nrb0 + i] = rows0 + rb1[i];
+      if (nl - rows0 == 0) nrb1 = 0;
+      if (rows0 == 0) { nrb0 = 0; }
+      free (rb0);
+      free (rb1);
+      V.color_rb[0] = 0;
+      V.color_rb[1] = nrb0;
+      V.color_rb[2] = nrb0 + nrb1;
+      V.L.n = nl;
+      V.L.nnz = prow[nl];
+      V.L.nrowblk = nrb0 + nrb1;
+      bool ok = upload (&V.L.rowptr, prow.data (), (size_t) nl + 1, &H.device_bytes) &&
+                upload (&V.L.colind, pcol.data (), (size_t) prow[nl], &H.device_bytes) &&
+                upload (&V.L.val, pval.data (), (size_t) prow[nl], &H.device_bytes) &&
+                upload (&V.L.rowblk, rb.data (), rb.size (), &H.device_bytes) &&
+                upload (&V.x, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
+                upload (&V.b, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
+                upload (&V.r, (const double *) nullptr, (size_t) nl, &H.device_bytes);
+      if (!ok) ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l);
+      if (l == 0 && !upload (&H.perm0, N.perm.data (), (size_t) nl, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+
+      if (l < nlev - 1) {
+         // column blocks of this level's operator
+         V.B.n = nl;
+         V.B.nblk = ncol;
+         if (!upload (&V.B.blk_start, pblk.data (), pblk.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+         int *dint = nullptr;
+         size_t dummy = 0;
+         std::vector<int> zeros (8, 0);
+         if (!upload (&dint, zeros.data (), 8, &dummy)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+         launch_colblock_measure (V.L, V.B, dint, st);
+         int meas[3];
+         (void) hipMemcpyAsync (meas, dint, sizeof meas, hipMemcpyDeviceToHost, st);
+         (void) hipStreamSynchronize (st);
+         if (meas[1] > 0) { (void) hipFree (dint); ML_FAIL (-4, "multilevel setup: level %d has %d rows without a diagonal entry", l, meas[1]); }
+         V.B.max_len = meas[2];
+         V.B.P = meas[0] <= 1 ? 1 : meas[0] <= 2 ? 2 : 4;
+         if (!upload (&V.B.fac, (const double *) nullptr, (size_t) (2 * V.B.P + 1) * (size_t) nl, &H.device_bytes)) { (void) hipFree (dint); ML_FAIL (-2, "multilevel setup: device allocation failed"); }
+         (void) hipMemsetAsync (dint, 0, 8 * sizeof (int), st);
+         launch_colblock_factor (V.L, V.B, dint, st);
+         int st2[2];
+         (void) hipMemcpyAsync (st2, dint, sizeof st2, hipMemcpyDeviceToHost, st);
+         (void) hipStreamSynchronize (st);
+         (void) hipFree (dint);
+         if (st2[0] != 0) ML_FAIL (-4, "multilevel setup: zero pivot in a column block of level %d (row %d)", l, st2[0] - 1);
+         V.B.dropped = st2[1];
+         // transfer operators in permuted orders
+         Nat &C = nat[l + 1];
+         const int64_t nc = C.L.n;
+         V.nc = nc;
+         std::vector<int> cmap_p (nl);
+         for (int64_t i = 0; i < nl; i++) cmap_p[i] = C.inv[N.cmap[N.perm[i]]];
+         std::vector<int> rptr (nc + 1, 0), ridx (nl);
+         for (int64_t i = 0; i < nl; i++) rptr[cmap_p[i] + 1]++;
+         for (int64_t I = 0; I < nc; I++) rptr[I + 1] += rptr[I];
+         {
+            std::vector<int> fill (rptr.begin (), rptr.end () - 1);
+            for (int64_t i = 0; i < nl; i++) ridx[fill[cmap_p[i]]++] = (int) i;
+         }
+         if (!(upload (&V.cmap, cmap_p.data (), (size_t) nl, &H.device_bytes) && upload (&V.rptr, rptr.data (), (size_t) nc + 1, &H.device_bytes) &&
+               upload (&V.ridx, ridx.data (), (size_t) nl, &H.device_bytes)))
+            ML_FAIL (-2, "multilevel setup: device allocation failed");
+      } else {
+         // coarsest level: dense inverse (permuted order)
+         if (nl > 6000) ML_FAIL (-1, "multilevel setup: coarsest level still has %lld rows; raise ml_levels", (long long) nl);
+         std::vector<double> dense ((size_t) nl * nl, 0.0);
+         for (int64_t i = 0; i < nl; i++)
+            for (int e = prow[i]; e < prow[i + 1]; e++) dense[(size_t) i * nl + pcol[e]] = pval[e];
+         if (!dense_inverse ((int) nl, dense)) ML_FAIL (-4, "multilevel setup: coarsest operator is singular");
+         if (!upload (&H.coarse_inv, dense.data (), dense.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+      }
+      if (verbose)
+         printf ("(%d) multilevel: level %d: %lld rows, %lld entries, %d columns (%d + %d by colour)%s\n", rank, l, (long long) nl,
+                 (long long) prow[nl], ncol, N.ncol0, ncol - N.ncol0, l == nlev - 1 ? ", dense solve" : "");
+   }
+   if (verbose) fflush (stdout);
+   return 0;
+#undef ML_FAIL
+}
+
+void ml_free (MlHierarchy &H)
+{
+   for (MlLevel &V : H.lev) {
+      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.rowblk, V.B.blk_start, V.B.fac, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
+      for (void *p : ptrs)
+         if (p) (void) hipFree (p);
+   }
+   H.lev.clear ();
+   if (H.perm0) (void) hipFree (H.perm0);
+   if (H.coarse_inv) (void) hipFree (H.coarse_inv);
+   H.perm0 = nullptr;
+   H.coarse_inv = nullptr;
+}
+
+// ================================================================ cycle
+static void gs_sweep (MlLevel &V, bool reverse, hipStream_t st)
+{
+   for (int step = 0; step < 2; step++) {
+      const int c = reverse ? 1 - step : step;
+      launch_csr_residual_range (V.L, V.color_rb[c], V.color_rb[c + 1], V.x, V.b, V.r, st);
+      launch_colblock_apply_range (V.B, V.color_blk[c], V.color_blk[c + 1], V.r, V.x, 1, st);
+   }
+}
+
+static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
+{
+   MlLevel &V = H.lev[l];
+   if (l == (int) H.lev.size () - 1) {
+      launch_dense_matvec (H.coarse_inv, V.b, V.x, (int) V.n, st);
+      return;
+   }
+   // pre-smoothing from x = 0: the first half-sweep needs no SpMV (r = b on colour 0)
+   launch_fill (V.x, 0.0, V.n, st);
+   launch_colblock_apply_range (V.B, V.color_blk[0], V.color_blk[1], V.b, V.x, 0, st);
+   launch_csr_residual_range (V.L, V.color_rb[1], V.color_rb[2], V.x, V.b, V.r, st);
+   launch_colblock_apply_range (V.B, V.color_blk[1], V.color_blk[2], V.r, V.x, 1, st);
+   for (int s = 1; s < H.nu; s++) gs_sweep (V, false, st);
+   // coarse-grid correction
+   launch_csr_spmv (V.L, V.x, V.r, V.b, 1, st);
+   MlLevel &C = H.lev[l + 1];
+   launch_restrict_sum (V.rptr, V.ridx, V.r, C.b, V.nc, st);
+   ml_cycle (H, l + 1, st);
+   launch_prolong_add (V.cmap, C.x, V.x, V.n, st);
+   for (int s = 0; s < H.nu; s++) gs_sweep (V, true, st);
+}
+
+void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st)
+{
+   MlLevel &V = H.lev[0];
+   launch_gather (H.perm0, r, V.b, V.n, st);
+   ml_cycle (H, 0, st);
+   launch_scatter (H.perm0, V.x, z, V.n, st);
+}

@@ -20,6 +20,8 @@ struct CsrDev {
 
 // y = A x (mode 0) or y = b - A x (mode 1)
 void launch_csr_spmv (const CsrDev &A, const double *x, double *y, const double *b, int mode, hipStream_t st);
+// rows of the row blocks [rb0, rb1) only: y_rows = b_rows - (A x)_rows  (Gauss-Seidel colour sweep)
+void launch_csr_residual_range (const CsrDev &A, int rb0, int rb1, const double *x, const double *b, double *y, hipStream_t st);
 // y = |A| |x| + |b|   (denominator of the componentwise backward error)
 void launch_csr_abs_spmv (const CsrDev &A, const double *x, const double *b, double *y, hipStream_t st);
 // host helper: greedy row-block partition (host arrays)
@@ -45,6 +47,8 @@ void launch_colblock_measure (const CsrDev &A, const ColBlocksDev &B, int *d_out
 void launch_colblock_factor (const CsrDev &A, ColBlocksDev &B, int *d_status, hipStream_t st);
 // z = M^-1 r
 void launch_colblock_apply (const ColBlocksDev &B, const double *r, double *z, hipStream_t st);
+// blocks [b0, b1) only; accumulate: z_blk += M_blk^-1 r_blk, else z_blk = M_blk^-1 r_blk
+void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, hipStream_t st);
 
 // ---------------------------------------------------------------- BLAS-1 style kernels
 #define NKP_RED_BLOCKS 1024        // partial sums per reduction (fixed => deterministic)
@@ -70,3 +74,15 @@ void launch_finish_column (double *h, const double *h2, int k, const double *nrm
 void launch_axpby (double a, const double *x, double b, double *y, int64_t n, hipStream_t st);
 void launch_copy (const double *x, double *y, int64_t n, hipStream_t st);
 void launch_fill (double *y, double v, int64_t n, hipStream_t st);
+
+// ---------------------------------------------------------------- grid transfer / permutation
+// coarse[I] = sum_{q in [rptr[I], rptr[I+1])} fine[ridx[q]]   (restriction = P^T, fixed order)
+void launch_restrict_sum (const int *rptr, const int *ridx, const double *fine, double *coarse, int64_t nc, hipStream_t st);
+// fine[i] += coarse[cmap[i]]                                  (prolongation = P)
+void launch_prolong_add (const int *cmap, const double *coarse, double *fine, int64_t nf, hipStream_t st);
+// out[i] = in[perm[i]]
+void launch_gather (const int *perm, const double *in, double *out, int64_t n, hipStream_t st);
+// out[perm[i]] = in[i]
+void launch_scatter (const int *perm, const double *in, double *out, int64_t n, hipStream_t st);
+// y = Minv x, dense row-major n x n (coarsest level)
+void launch_dense_matvec (const double *Minv, const double *x, double *y, int n, hipStream_t st);

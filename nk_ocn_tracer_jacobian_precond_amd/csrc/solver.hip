@@ -9,6 +9,7 @@
 // device and fails with NKP_EDEVICE otherwise.
 #include "../../include/nkp.h"
 #include "nkp_dev.h"
+#include "multilevel.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -52,7 +53,7 @@ extern "C" int nkp_default_options (nkp_options *opt)
    if (!opt) return NKP_EINVAL;
    memset (opt, 0, sizeof *opt);
    opt->struct_size = (int) sizeof (nkp_options);
-   opt->precond = NKP_PRECOND_COLUMN_JACOBI;
+   opt->precond = NKP_PRECOND_MULTILEVEL;
    opt->krylov = NKP_KRYLOV_FGMRES;
    opt->restart = 100;
    opt->max_iters = 20000;
@@ -63,7 +64,7 @@ extern "C" int nkp_default_options (nkp_options *opt)
    opt->rank = 0;
    opt->reorth = 1;
    opt->ml_levels = 0;
-   opt->ml_smooth = 1;
+   opt->ml_smooth = 2;
    return NKP_OK;
 }
 
@@ -75,6 +76,7 @@ struct nkp_solver {
    bool own_stream = false;
    CsrDev A;
    ColBlocksDev B;
+   MlHierarchy ml;
    int64_t n = 0, ld = 0;
    int m = 0;
    // work vectors
@@ -109,6 +111,7 @@ static void solver_free (nkp_solver *s)
                     s->x, s->b, s->t1, s->t2, s->partial, s->dscal, s->dint };
    for (void *p : ptrs)
       if (p) (void) hipFree (p);
+   ml_free (s->ml);
    if (s->hpin) (void) hipHostFree (s->hpin);
    if (s->own_stream && s->stream) (void) hipStreamDestroy (s->stream);
    delete s;
@@ -130,6 +133,7 @@ static void msg (const nkp_solver *s, int lvl, const char *fmt, ...)
 static void apply_precond (nkp_solver *s, const double *rin, double *zout)
 {
    if (s->opt.precond == NKP_PRECOND_NONE) launch_copy (rin, zout, s->n, s->stream);
+   else if (s->opt.precond == NKP_PRECOND_MULTILEVEL) ml_apply (s->ml, rin, zout, s->stream);
    else launch_colblock_apply (s->B, rin, zout, s->stream);
 }
 
@@ -137,7 +141,6 @@ extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t 
                            const int32_t *rowptr, const int32_t *colind, const double *val,
                            const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt)
 {
-   (void) coupled_tracer_cnt;
    if (!out) return fail (NKP_EINVAL, "nkp_create: out is NULL");
    *out = nullptr;
    nkp_options opt;
@@ -158,6 +161,9 @@ extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t 
       if (rowptr[r + 1] < rowptr[r]) return fail (NKP_EINVAL, "nkp_create: rowptr decreases at row %lld", (long long) r);
       for (int e = rowptr[r]; e < rowptr[r + 1]; e++)
          if (colind[e] < 0 || colind[e] >= n) return fail (NKP_EINVAL, "nkp_create: column index %d out of range in row %lld", colind[e], (long long) r);
+      if (opt.precond == NKP_PRECOND_MULTILEVEL)
+         for (int e = rowptr[r] + 1; e < rowptr[r + 1]; e++)
+            if (colind[e] <= colind[e - 1]) return fail (NKP_EINVAL, "nkp_create: row %lld is not sorted by column (the multilevel setup needs the sorted rows gen_A writes)", (long long) r);
    }
    std::vector<int> blk_default;
    if (opt.precond != NKP_PRECOND_NONE) {
@@ -237,8 +243,18 @@ extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t 
    TRYHIP (hipHostMalloc ((void **) &s->hpin, (size_t) (m + 16) * sizeof (double), hipHostMallocDefault));
    TRYHIP (hipMemset (s->dscal, 0, (size_t) (3 * (m + 2) + 16 + 8) * sizeof (double)));
 
+   if (opt.precond == NKP_PRECOND_MULTILEVEL) {
+      char err[256] = "";
+      const int mrc = ml_setup (s->ml, n, rowptr, colind, val, blk_start, nblk, blk_default.empty () ? opt.col_i : nullptr, blk_default.empty () ? opt.col_j : nullptr, coupled_tracer_cnt, opt.ml_levels, opt.ml_smooth, 1500, opt.verbose, opt.rank, s->stream, err, sizeof err);
+      if (mrc != 0) {
+         rc = fail (mrc, "nkp_create: %s", err);
+         solver_free (s);
+         return rc;
+      }
+      s->device_bytes += s->ml.device_bytes;
+   }
    // water-column blocks
-   if (opt.precond != NKP_PRECOND_NONE) {
+   if (opt.precond == NKP_PRECOND_COLUMN_JACOBI) {
       s->B.n = n;
       s->B.nblk = (int) nblk;
       TRY (dev_alloc (s, &s->B.blk_start, (size_t) nblk + 1));
@@ -297,7 +313,9 @@ extern "C" int64_t nkp_get_int (nkp_solver *s, const char *key)
    if (!strcmp (key, "nblk")) return s->B.nblk;
    if (!strcmp (key, "band")) return s->B.P;
    if (!strcmp (key, "band_dropped")) return s->B.dropped;
-   if (!strcmp (key, "levels")) return 1;
+   if (!strcmp (key, "levels")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? (int64_t) s->ml.lev.size () : 1;
+   if (!strcmp (key, "ml_rows")) { int64_t t = 0; for (auto &v : s->ml.lev) t += v.n; return t; }
+   if (!strcmp (key, "ml_nnz")) { int64_t t = 0; for (auto &v : s->ml.lev) t += v.L.nnz; return t; }
    if (!strcmp (key, "rowblocks")) return s->A.nrowblk;
    if (!strcmp (key, "spmv_bytes")) return 12 * s->A.nnz + 4 * (s->n + 1) + 16 * s->n;
    if (!strcmp (key, "precond_bytes")) return s->opt.precond == NKP_PRECOND_NONE ? 16 * s->n : (int64_t) (2 * s->B.P + 1) * 8 * s->n + 16 * s->n;

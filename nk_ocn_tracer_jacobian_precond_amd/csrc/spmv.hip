@@ -21,7 +21,7 @@
 
 template <int MODE>   // 0: y = A x   1: y = b - A x   2: y = |A||x| + |b|
 __global__ __launch_bounds__ (SPMV_THREADS)
-void csr_spmv_stream_kernel (const int *__restrict__ rowblk, int nrowblk, int per_xcd,
+void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk, int per_xcd,
                              const int *__restrict__ rowptr, const int *__restrict__ colind,
                              const double *__restrict__ val, const double *__restrict__ x,
                              double *__restrict__ y, const double *__restrict__ b)
@@ -35,6 +35,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk, int nrowblk, int pe
    if (idx >= per_xcd || lb >= nrowblk) return;
 
    const int tid = threadIdx.x;
+   const int *rowblk = rowblk_all + rb0;
    const int r0 = rowblk[lb], r1 = rowblk[lb + 1];
    const int e0 = rowptr[r0], e1 = rowptr[r1];
    const int cnt = e1 - e0;
@@ -105,7 +106,7 @@ static void launch_mode (const CsrDev &A, const double *x, double *y, const doub
    if (A.n == 0) return;
    const int per_xcd = (A.nrowblk + 7) / 8;
    hipLaunchKernelGGL ((csr_spmv_stream_kernel<MODE>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st,
-                       A.rowblk, A.nrowblk, per_xcd, A.rowptr, A.colind, A.val, x, y, b);
+                       A.rowblk, 0, A.nrowblk, per_xcd, A.rowptr, A.colind, A.val, x, y, b);
 }
 
 void launch_csr_spmv (const CsrDev &A, const double *x, double *y, const double *b, int mode, hipStream_t st)
@@ -117,4 +118,13 @@ void launch_csr_spmv (const CsrDev &A, const double *x, double *y, const double 
 void launch_csr_abs_spmv (const CsrDev &A, const double *x, const double *b, double *y, hipStream_t st)
 {
    launch_mode<2> (A, x, y, b, st);
+}
+
+void launch_csr_residual_range (const CsrDev &A, int rb0, int rb1, const double *x, const double *b, double *y, hipStream_t st)
+{
+   const int cnt = rb1 - rb0;
+   if (cnt <= 0) return;
+   const int per_xcd = (cnt + 7) / 8;
+   hipLaunchKernelGGL ((csr_spmv_stream_kernel<1>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st,
+                       A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.val, x, y, b);
 }

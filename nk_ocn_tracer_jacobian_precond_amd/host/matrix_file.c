@@ -246,3 +246,19 @@ void nkp_rowblock_partition (int n, int nprocs, int rank, int *fst_row, int *m_l
    *fst_row = rank * base;
    *m_loc = (rank == nprocs - 1) ? n - *fst_row : base;
 }
+
+/* grid position (i, j) of every block returned by nkp_column_blocks, same order; 0 = ok */
+int nkp_column_coords (int nblk, int *col_i, int *col_j)
+{
+   int b = 0;
+   int cnt = coupled_tracer_cnt > 0 ? coupled_tracer_cnt : 1;
+   for (int t = 0; t < cnt; t++)
+      for (int s = 0; s < tracer_state_len; s++)
+         if (tracer_state_ind_to_int3[s].k == 0) {
+            if (b >= nblk) return 1;
+            col_i[b] = tracer_state_ind_to_int3[s].i;
+            col_j[b] = tracer_state_ind_to_int3[s].j;
+            b++;
+         }
+   return b == nblk ? 0 : 1;
+}

@@ -93,6 +93,8 @@ void free_sparse_matrix (void);
  * src/matrix.c:239-251).  With coupled tracers (tracer-major rows, src/matrix.c:778-784)
  * the pattern repeats per tracer.  Returns a malloc'd array of *nblk + 1 row offsets. */
 int_t *nkp_column_blocks (int *nblk);
+/* Grid position (i, j) of each of those blocks (its first row's index-map entry); 0 = ok. */
+int nkp_column_coords (int nblk, int *col_i, int *col_j);
 
 /* B[t*tracer_state_len + s] = field[k_s][j_s][i_s]  (reference src/solve_ABglobal.c:184-191)
  * and its inverse which leaves every non-ocean value of `field` untouched (:242-248). */

@@ -34,7 +34,8 @@ class NkpOptions(C.Structure):
         ("struct_size", C.c_int), ("precond", C.c_int), ("krylov", C.c_int), ("restart", C.c_int),
         ("max_iters", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("device", C.c_int),
         ("verbose", C.c_int), ("rank", C.c_int), ("reorth", C.c_int), ("ml_levels", C.c_int),
-        ("ml_smooth", C.c_int), ("reserved", C.c_int * 8),
+        ("ml_smooth", C.c_int), ("reserved", C.c_int * 7),
+        ("col_i", C.POINTER(C.c_int32)), ("col_j", C.POINTER(C.c_int32)),
     ]
 
 
@@ -101,7 +102,7 @@ def _p(a, t):
 class NkpSolver:
     """Device-resident solver for one CSR matrix (setup = the reference's factor-only call)."""
 
-    def __init__(self, rowptr, colind, val, blk_start=None, coupled_tracer_cnt=1, **options):
+    def __init__(self, rowptr, colind, val, blk_start=None, coupled_tracer_cnt=1, col_i=None, col_j=None, **options):
         self._lib = load_library()
         self._h = C.c_void_p()
         rowptr = np.ascontiguousarray(rowptr, np.int32)
@@ -111,6 +112,12 @@ class NkpSolver:
         self.nnz = int(colind.size)
         opt = default_options(**options)
         self.options = opt
+        if col_i is not None and col_j is not None:
+            col_i = np.ascontiguousarray(col_i, np.int32)
+            col_j = np.ascontiguousarray(col_j, np.int32)
+            if blk_start is None or col_i.size != len(blk_start) - 1 or col_j.size != col_i.size:
+                raise ValueError("col_i / col_j need one entry per block of blk_start")
+            opt.col_i, opt.col_j = _p(col_i, C.c_int32), _p(col_j, C.c_int32)
         if blk_start is not None:
             blk_start = np.ascontiguousarray(blk_start, np.int32)
             bp, nb = _p(blk_start, C.c_int32), blk_start.size - 1
@@ -199,6 +206,14 @@ class NkpSolver:
 
 def device_count():
     return int(load_library().nkp_device_count())
+
+
+def column_coords(ind_i, ind_j, col_start, coupled_tracer_cnt=1):
+    """(i, j) of every block of column_blocks(...): the index maps at each column's first row."""
+    first = np.asarray(col_start[:-1], np.int64)
+    ci = np.tile(np.asarray(ind_i)[first], coupled_tracer_cnt).astype(np.int32)
+    cj = np.tile(np.asarray(ind_j)[first], coupled_tracer_cnt).astype(np.int32)
+    return ci, cj
 
 
 def column_blocks(col_start, tracer_state_len, coupled_tracer_cnt=1):

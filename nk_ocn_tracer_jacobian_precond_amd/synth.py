@@ -144,7 +144,7 @@ _SLOTS_ISOP = [(1, 0, -1), (1, 0, 1), (-1, 0, -1), (-1, 0, 1), (0, 1, -1), (0, 1
 
 def generate(imt=12, jmt=10, km=6, seed=0, adv="centred", hmix="const", coupled_tracer_cnt=1,
              day_cnt=365.0, u_scale=3.0, noise=0.3, ah=4.0e6, vdc_bg=0.1, vdc_ml=1000.0,
-             sink_rate=365.0, sink_depth=10.0e2, dtype_check=True):
+             sink_rate=365.0, sink_depth=10.0e2, min_cos=0.3):
     """Build a SynthProblem.  adv in {none, donor, centred, upwind3}; hmix in {const, isop}."""
     rng = np.random.default_rng(seed + 1000)
     dz = pop_like_dz(km)
@@ -156,11 +156,13 @@ def generate(imt=12, jmt=10, km=6, seed=0, adv="centred", hmix="const", coupled_
     R = 6.37122e8
     dlam = np.deg2rad(360.0 / imt)
     dphi = np.deg2rad(168.0 / jmt)
-    coslat = np.cos(np.deg2rad(lat))
+    # POP's displaced-pole grids have no polar singularity: zonal spacing never collapses the way a
+    # regular lat-lon grid's does, so the metric floors cos(lat) at min_cos
+    coslat = np.maximum(np.cos(np.deg2rad(lat)), min_cos)
     dx = (R * coslat * dlam)[None, :, None]                      # T-cell width        [1,j,1]
     dy = np.full((1, jmt, 1), R * dphi)
     latn = np.deg2rad(lat + 0.5 * 168.0 / jmt)
-    dxn = (R * np.cos(latn) * dlam)[None, :, None]               # north-face length
+    dxn = (R * np.maximum(np.cos(latn), min_cos) * dlam)[None, :, None]   # north-face length
     TAREA = dx * dy
 
     kk = np.arange(km)[:, None, None]
@@ -355,7 +357,8 @@ def generate(imt=12, jmt=10, km=6, seed=0, adv="centred", hmix="const", coupled_
     return SynthProblem(imt, jmt, km, cnt, tsl, KMT, z_t, dz, TLONG, TLAT, IDX, ind_i, ind_j, ind_k,
                         rowptr.astype(np.int32), colind, nzval,
                         meta=dict(seed=seed, adv=adv, hmix=hmix, day_cnt=day_cnt, u_scale=u_scale, noise=noise,
-                                  ah=ah, vdc_bg=vdc_bg, vdc_ml=vdc_ml, sink_rate=sink_rate, sink_depth=sink_depth))
+                                  ah=ah, vdc_bg=vdc_bg, vdc_ml=vdc_ml, sink_rate=sink_rate, sink_depth=sink_depth,
+                                  min_cos=min_cos))
 
 
 def write_matrix_file(p: SynthProblem, path, version=2):

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_default_options():
     o = solver.default_options()
     assert o.struct_size == C.sizeof(solver.NkpOptions)
-    assert (o.precond, o.krylov, o.rtol) == (solver.PRECOND_COLUMN_JACOBI, solver.KRYLOV_FGMRES, 1e-10)
+    assert (o.precond, o.krylov, o.rtol) == (solver.PRECOND_MULTILEVEL, solver.KRYLOV_FGMRES, 1e-10)
 
 
 def test_argument_validation_needs_no_gpu():
