@@ -263,3 +263,237 @@ void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const d
    if (b1 <= b0) return;
    CB_DISPATCH_N (colblock_apply_kernel, b1 - b0, B.blk_start, b0, b1, B.n, B.fac, r, z, accumulate);
 }
+
+// ================================================================ lane-per-column apply
+// The wave-per-column substitution above is VALU-issue bound: 2*len dependent steps of
+// readlane + predicated FMA per column (rocprof: 137 us per half sweep at 1 degree against ~25 us
+// of HBM time).  Here one LANE owns one column: a wave stages the right-hand side of 64
+// consecutive columns (a contiguous row range) into LDS with coalesced loads, every lane then
+// runs its own short recurrence with the factors stored [diagonal][step k][lane] so that each
+// step is one coalesced 512-byte load per diagonal, and the result goes back coalesced.
+// 64x fewer wave-instructions per column; same operation order as the sequential kernel and
+// the oracle, so results are bit-identical.
+#include <stdlib.h>
+#include <vector>
+
+#define LDS_PAD(i) ((i) + ((i) >> 5))       // break the lane stride (column length) bank pattern
+
+__global__ __launch_bounds__ (NKP_WAVE)
+void colblock_transpose_kernel (const int *__restrict__ blk_start, const int *__restrict__ grp_b0, const int *__restrict__ grp_nb,
+                                const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int ndiag, int64_t n,
+                                const double *__restrict__ fac, double *__restrict__ fac_t, int gw)
+{
+   const int g = blockIdx.x;
+   const int lane = threadIdx.x;
+   const int b0 = grp_b0[g], nb = grp_nb[g], ml = grp_maxlen[g];
+   double *ft = fac_t + grp_base[g];
+   int r0 = 0, len = 0;
+   if (lane < nb) { r0 = blk_start[b0 + lane]; len = blk_start[b0 + lane + 1] - r0; }
+   if (lane >= gw) return;
+   for (int d = 0; d < ndiag; d++)
+      for (int k = 0; k < ml; k++)
+         ft[((int64_t) d * ml + k) * gw + lane] = (k < len) ? fac[(int64_t) d * n + r0 + k] : 0.0;
+}
+
+template <int P, int MAXL>
+__global__ __launch_bounds__ (NKP_WAVE)
+void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *__restrict__ grp_b0, const int *__restrict__ grp_nb,
+                                  const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
+                                  const double *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
+                                  int gw, int rhs_slots)
+{
+   extern __shared__ double lds[];            // [rhs_slots] staged right-hand side | [(2P+1)*ml*gw] the group's factors
+   const int g = blockIdx.x + g_first;
+   const int lane = threadIdx.x;
+   const int b0 = grp_b0[g], nb = grp_nb[g], ml = grp_maxlen[g];
+   const int R0 = blk_start[b0], R1 = blk_start[b0 + nb];
+   const int nrows = R1 - R0;
+   double *fl = lds + rhs_slots;
+   // bulk, fully coalesced staging: every load is independent, so the whole group is in flight at once
+   {
+      const double2 *src = reinterpret_cast<const double2 *> (fac_t + grp_base[g]);
+      double2 *dst = reinterpret_cast<double2 *> (fl);
+      const int cnt2 = ((2 * P + 1) * ml * gw) >> 1;
+      // batches of 8 loads in flight per lane before the first LDS store waits on them
+      for (int i0 = lane; i0 < cnt2; i0 += 8 * NKP_WAVE) {
+         double2 t[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * NKP_WAVE;
+            t[u] = (i < cnt2) ? src[i] : make_double2 (0.0, 0.0);
+         }
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * NKP_WAVE;
+            if (i < cnt2) dst[i] = t[u];
+         }
+      }
+   }
+   for (int i0 = lane; i0 < nrows; i0 += 8 * NKP_WAVE) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         const int i = i0 + u * NKP_WAVE;
+         t[u] = (i < nrows) ? rhs[(int64_t) R0 + i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         const int i = i0 + u * NKP_WAVE;
+         if (i < nrows) lds[LDS_PAD (i)] = t[u];
+      }
+   }
+   __syncthreads ();
+
+   if (lane < nb) {
+      const int s = blk_start[b0 + lane] - R0;
+      const int len = blk_start[b0 + lane + 1] - blk_start[b0 + lane];
+      const double *ft = fl + lane;
+      const int dstride = ml * gw;
+      // the whole column lives in registers: no LDS write sits between two LDS reads, so the compiler
+      // can keep the (read-only) factor reads in flight ahead of the dependent arithmetic
+      double v[MAXL];
+#pragma unroll
+      for (int k = 0; k < MAXL; k++) v[k] = (k < len) ? lds[LDS_PAD (s + k)] : 0.0;
+      // forward: y_k = ((r_k - l(k,k-P) y_{k-P}) ... - l(k,k-1) y_{k-1})   (far diagonal first, like the column sweep)
+      // steps k >= len need no predicate: their factors are zero-padded, so they compute 0 - 0*x = 0;
+      // the only branch left is wave-uniform (k < ml), which keeps the LDS reads hoistable
+#pragma unroll
+      for (int k = 0; k < MAXL; k++) {
+         if (k < ml) {
+            double y = v[k];
+#pragma unroll
+            for (int q = P; q >= 1; q--)
+               if (k - q >= 0) y -= ft[(P - q) * dstride + k * gw] * v[k - q];
+            v[k] = y;
+         }
+      }
+      // backward: x_k = (((y_k - u(k,k+P) x_{k+P}) ... - u(k,k+1) x_{k+1}) * (1/u_kk)
+#pragma unroll
+      for (int k = MAXL - 1; k >= 0; k--) {
+         if (k < ml) {
+            double x = v[k];
+#pragma unroll
+            for (int q = P; q >= 1; q--)
+               if (k + q < MAXL) x -= ft[(P + q) * dstride + k * gw] * v[k + q];
+            x *= ft[P * dstride + k * gw];
+            v[k] = x;
+         }
+      }
+#pragma unroll
+      for (int k = 0; k < MAXL; k++)
+         if (k < len) lds[LDS_PAD (s + k)] = v[k];
+   }
+   __syncthreads ();
+   if (accumulate) {
+      for (int i0 = lane; i0 < nrows; i0 += 8 * NKP_WAVE) {
+         double t[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * NKP_WAVE;
+            t[u] = (i < nrows) ? z[(int64_t) R0 + i] : 0.0;
+         }
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * NKP_WAVE;
+            if (i < nrows) z[(int64_t) R0 + i] = t[u] + lds[LDS_PAD (i)];
+         }
+      }
+   } else
+      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
+}
+
+template <class T>
+static int up (T **dst, const std::vector<T> &src, size_t *bytes)
+{
+   void *q = nullptr;
+   const size_t b = (src.size () ? src.size () : 1) * sizeof (T);
+   hipError_t e = hipMalloc (&q, b);
+   if (e != hipSuccess) return (int) e;
+   if (!src.empty ()) {
+      e = hipMemcpy (q, src.data (), src.size () * sizeof (T), hipMemcpyHostToDevice);
+      if (e != hipSuccess) { (void) hipFree (q); return (int) e; }
+   }
+   *dst = (T *) q;
+   *bytes += b;
+   return 0;
+}
+
+int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const int *ranges, int nranges,
+                                int *grp_first, size_t *device_bytes, hipStream_t st)
+{
+   std::vector<int> b0, nb, ml;
+   std::vector<long long> base;
+   // columns per wave: the group's factors + right-hand side must fit LDS several times per CU
+   int gw = 8;
+   if (const char *e = getenv ("NKP_COLGROUP")) gw = atoi (e);
+   if (gw != 8 && gw != 16 && gw != 32 && gw != 64) gw = 8;
+   while (gw > 8 && (size_t) ((2 * B.P + 2) * B.max_len * gw) * sizeof (double) > 56 * 1024) gw >>= 1;
+   B.gw = gw;
+   long long total = 0;
+   int lds_need = 0, fac_need = 0;
+   const int ndiag = 2 * B.P + 1;
+   for (int r = 0; r < nranges; r++) {
+      grp_first[r] = (int) b0.size ();
+      for (int b = ranges[r]; b < ranges[r + 1]; b += gw) {
+         const int cnt = std::min (gw, ranges[r + 1] - b);
+         int m = 0;
+         for (int c = b; c < b + cnt; c++) m = std::max (m, h_blk_start[c + 1] - h_blk_start[c]);
+         const int rows = h_blk_start[b + cnt] - h_blk_start[b];
+         lds_need = std::max (lds_need, LDS_PAD (rows) + 2);
+         fac_need = std::max (fac_need, ndiag * m * gw);
+         b0.push_back (b);
+         nb.push_back (cnt);
+         ml.push_back (m);
+         base.push_back (total);
+         total += (long long) ndiag * m * gw;
+      }
+   }
+   grp_first[nranges] = (int) b0.size ();
+   B.ngrp = (int) b0.size ();
+   lds_need = (lds_need + 1) & ~1;                 // keep the factor area 16-byte aligned
+   B.rhs_slots = lds_need;
+   lds_need += fac_need;
+   B.lds_doubles = lds_need;
+   int rc;
+   if ((rc = up (&B.grp_b0, b0, device_bytes)) || (rc = up (&B.grp_nb, nb, device_bytes)) || (rc = up (&B.grp_maxlen, ml, device_bytes)) ||
+       (rc = up (&B.grp_base, base, device_bytes)))
+      return rc;
+   void *q = nullptr;
+   hipError_t e = hipMalloc (&q, (size_t) (total ? total : 1) * sizeof (double));
+   if (e != hipSuccess) return (int) e;
+   B.fac_t = (double *) q;
+   *device_bytes += (size_t) total * sizeof (double);
+   if (B.ngrp)
+      hipLaunchKernelGGL (colblock_transpose_kernel, dim3 (B.ngrp), dim3 (NKP_WAVE), 0, st, B.blk_start, B.grp_b0, B.grp_nb, B.grp_maxlen,
+                          B.grp_base, ndiag, B.n, B.fac, B.fac_t, gw);
+   // dynamic LDS above the default limit needs an explicit opt-in
+   const int lds_bytes = lds_need * (int) sizeof (double);
+   if (lds_bytes > 160 * 1024) return (int) hipErrorInvalidValue;
+   if (lds_bytes > 48 * 1024) {
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+   }
+   return (int) hipStreamSynchronize (st);
+}
+
+void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const double *r, double *z, int accumulate, hipStream_t st)
+{
+   if (g1 <= g0) return;
+   const size_t lds = (size_t) B.lds_doubles * sizeof (double);
+#define LANES_LAUNCH(PP)                                                                                                   \
+   do {                                                                                                                    \
+      if (B.max_len <= 64) LANES_LAUNCH2 (PP, 64);                                                                         \
+      else LANES_LAUNCH2 (PP, 128);                                                                                        \
+   } while (0)
+#define LANES_LAUNCH2(PP, ML) hipLaunchKernelGGL ((colblock_apply_lanes_kernel<PP, ML>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.blk_start, B.grp_b0, \
+                                              B.grp_nb, B.grp_maxlen, B.grp_base, g0, B.fac_t, r, z, accumulate, B.gw, B.rhs_slots)
+   if (B.P == 1) LANES_LAUNCH (1);
+   else if (B.P == 2) LANES_LAUNCH (2);
+   else LANES_LAUNCH (4);
+#undef LANES_LAUNCH
+#undef LANES_LAUNCH2
+}

@@ -10,6 +10,7 @@ struct MlLevel {
    ColBlocksDev B;              // factored water-column blocks of L (absent on the coarsest level)
    int color_rb[3] = { 0, 0, 0 };    // SpMV row blocks of colour c: [color_rb[c], color_rb[c+1])
    int color_blk[3] = { 0, 0, 0 };   // column blocks of colour c
+   int color_grp[3] = { 0, 0, 0 };   // lane-per-column groups of colour c
    int64_t nc = 0;              // rows of the next coarser level
    int *cmap = nullptr;         // fine row -> coarse row                 (prolongation)
    int *rptr = nullptr, *ridx = nullptr;   // coarse row -> its fine rows (restriction)

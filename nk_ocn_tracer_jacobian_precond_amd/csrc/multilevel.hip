@@ -488,6 +488,11 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          (void) hipFree (dint);
          if (st2[0] != 0) ML_FAIL (-4, "multilevel setup: zero pivot in a column block of level %d (row %d)", l, st2[0] - 1);
          V.B.dropped = st2[1];
+         {
+            const int ranges[3] = { 0, N.ncol0, ncol };
+            const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st);
+            if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
+         }
          // transfer operators in permuted orders
          Nat &C = nat[l + 1];
          const int64_t nc = C.L.n;
@@ -525,7 +530,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 void ml_free (MlHierarchy &H)
 {
    for (MlLevel &V : H.lev) {
-      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.rowblk, V.B.blk_start, V.B.fac, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
+      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.rowblk, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.fac_t, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
       for (void *p : ptrs)
          if (p) (void) hipFree (p);
    }
@@ -542,7 +547,7 @@ static void gs_sweep (MlLevel &V, bool reverse, hipStream_t st)
    for (int step = 0; step < 2; step++) {
       const int c = reverse ? 1 - step : step;
       launch_csr_residual_range (V.L, V.color_rb[c], V.color_rb[c + 1], V.x, V.b, V.r, st);
-      launch_colblock_apply_range (V.B, V.color_blk[c], V.color_blk[c + 1], V.r, V.x, 1, st);
+      launch_colblock_apply_lanes (V.B, V.color_grp[c], V.color_grp[c + 1], V.r, V.x, 1, st);
    }
 }
 
@@ -555,9 +560,9 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
    }
    // pre-smoothing from x = 0: the first half-sweep needs no SpMV (r = b on colour 0)
    launch_fill (V.x, 0.0, V.n, st);
-   launch_colblock_apply_range (V.B, V.color_blk[0], V.color_blk[1], V.b, V.x, 0, st);
+   launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.b, V.x, 0, st);
    launch_csr_residual_range (V.L, V.color_rb[1], V.color_rb[2], V.x, V.b, V.r, st);
-   launch_colblock_apply_range (V.B, V.color_blk[1], V.color_blk[2], V.r, V.x, 1, st);
+   launch_colblock_apply_lanes (V.B, V.color_grp[1], V.color_grp[2], V.r, V.x, 1, st);
    for (int s = 1; s < H.nu; s++) gs_sweep (V, false, st);
    // coarse-grid correction
    launch_csr_spmv (V.L, V.x, V.r, V.b, 1, st);

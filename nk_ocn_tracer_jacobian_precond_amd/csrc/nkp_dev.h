@@ -39,7 +39,26 @@ struct ColBlocksDev {
    int max_len = 0;            // longest block
    int dropped = 0;            // 1 if in-block entries beyond the band were dropped
    double *fac = nullptr;      // [(2P+1)*n]
+   // lane-per-column layout for the apply kernel: groups of <= 64 consecutive blocks; group g's
+   // factors live at fac_t + grp_base[g] as [(2P+1)][grp_maxlen[g]][64] (coalesced per step k)
+   int ngrp = 0;
+   int *grp_b0 = nullptr;      // [ngrp] first block of the group
+   int *grp_nb = nullptr;      // [ngrp] blocks in the group (<= 64)
+   int *grp_maxlen = nullptr;  // [ngrp] longest block of the group
+   long long *grp_base = nullptr;   // [ngrp] offset into fac_t (doubles)
+   double *fac_t = nullptr;
+   int lds_doubles = 0;        // LDS staging need of the largest group (padded)
+   int gw = 64;                // columns (lanes in use) per group
+   int rhs_slots = 0;          // LDS doubles reserved for the staged right-hand side
 };
+
+// Build the lane-per-column layout.  ranges: nranges+1 block offsets; a group never straddles a
+// range boundary (Gauss-Seidel colours).  grp_first[r] = first group of range r (nranges+1 out).
+// Returns 0 or a HIP error code cast to int.
+int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const int *ranges, int nranges,
+                                int *grp_first, size_t *device_bytes, hipStream_t st);
+// groups [g0, g1): z (+)= M^-1 r, one water column per LANE, rhs staged through LDS
+void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const double *r, double *z, int accumulate, hipStream_t st);
 
 // max over blocks of the in-block half bandwidth and of the block length (device reduction)
 void launch_colblock_measure (const CsrDev &A, const ColBlocksDev &B, int *d_out2 /* [bw, zero_diag_rows] */, hipStream_t st);

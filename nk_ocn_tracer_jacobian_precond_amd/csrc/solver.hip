@@ -107,7 +107,7 @@ static int dev_alloc (nkp_solver *s, T **p, size_t count)
 static void solver_free (nkp_solver *s)
 {
    if (!s) return;
-   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->B.blk_start, s->B.fac, s->V, s->Z, s->w, s->r,
+   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.fac_t, s->V, s->Z, s->w, s->r,
                     s->x, s->b, s->t1, s->t2, s->partial, s->dscal, s->dint };
    for (void *p : ptrs)
       if (p) (void) hipFree (p);
@@ -134,7 +134,7 @@ static void apply_precond (nkp_solver *s, const double *rin, double *zout)
 {
    if (s->opt.precond == NKP_PRECOND_NONE) launch_copy (rin, zout, s->n, s->stream);
    else if (s->opt.precond == NKP_PRECOND_MULTILEVEL) ml_apply (s->ml, rin, zout, s->stream);
-   else launch_colblock_apply (s->B, rin, zout, s->stream);
+   else launch_colblock_apply_lanes (s->B, 0, s->B.ngrp, rin, zout, 0, s->stream);
 }
 
 extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t n, int64_t nnz,
@@ -161,6 +161,13 @@ extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t 
       if (rowptr[r + 1] < rowptr[r]) return fail (NKP_EINVAL, "nkp_create: rowptr decreases at row %lld", (long long) r);
       for (int e = rowptr[r]; e < rowptr[r + 1]; e++)
          if (colind[e] < 0 || colind[e] >= n) return fail (NKP_EINVAL, "nkp_create: column index %d out of range in row %lld", colind[e], (long long) r);
+      if (opt.precond != NKP_PRECOND_NONE) {
+         bool have_diag = false;
+         for (int e = rowptr[r]; e < rowptr[r + 1]; e++)
+            if (colind[e] == r && val[e] != 0.0) have_diag = true;
+         if (!have_diag)
+            return fail (NKP_ESINGULAR, "nkp_create: row %lld has no (or a zero) diagonal entry; the water-column preconditioners need one (the reference only reports this: src/matrix.c:3692-3727)", (long long) r);
+      }
       if (opt.precond == NKP_PRECOND_MULTILEVEL)
          for (int e = rowptr[r] + 1; e < rowptr[r + 1]; e++)
             if (colind[e] <= colind[e - 1]) return fail (NKP_EINVAL, "nkp_create: row %lld is not sorted by column (the multilevel setup needs the sorted rows gen_A writes)", (long long) r);
@@ -283,6 +290,16 @@ extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t 
          return rc;
       }
       s->B.dropped = st2[1];
+      {
+         const int ranges[2] = { 0, (int) nblk };
+         int grp_first[2];
+         const int lrc = colblock_build_lane_layout (s->B, blk_start, ranges, 1, grp_first, &s->device_bytes, s->stream);
+         if (lrc != 0) {
+            rc = fail (NKP_EDEVICE, "nkp_create: lane layout of the column blocks failed (HIP error %d)", lrc);
+            solver_free (s);
+            return rc;
+         }
+      }
       msg (s, 1, "column blocks: %lld blocks, longest %d rows, in-block half bandwidth %d stored as %d%s\n", (long long) nblk,
            s->B.max_len, meas[0], s->B.P, s->B.dropped ? " (entries beyond the band dropped)" : "");
    }

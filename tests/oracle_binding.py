@@ -110,6 +110,8 @@ def fgmres(rowptr, colind, val, blk_start, b, precond=1, restart=100, max_iters=
     bs = np.ascontiguousarray(blk_start if blk_start is not None else np.arange(n + 1), np.int32)
     x = np.zeros(n)
     it, rr = C.c_int(), C.c_double()
+    # small systems: a handful of threads (128 OpenMP threads spinning on n = 300 take minutes)
+    lib().ora_set_num_threads(int(max(1, min(os.cpu_count() or 1, n // 20000))))
     rc = lib().ora_fgmres(n, rp, ci, v, bs.size - 1, bs, precond, restart, max_iters, rtol,
                           np.ascontiguousarray(b, np.float64), x, C.byref(it), C.byref(rr))
     return x, dict(status=rc, iters=it.value, relres=rr.value)
