@@ -141,19 +141,54 @@ const char *nkp_last_error (void);
 
 /* ---- row-distributed flavour (one process per GPU, RCCL over xGMI) --------------------- */
 
+/* What the distributed solver needs from the outside world: four collectives.  The library ships
+ * an RCCL implementation (nkp_comm_rccl_init); a host program that already owns a communicator
+ * (torch.distributed in bench.py, MPI in a port of src/solve_ABdist.c) passes its own callbacks.
+ * All callbacks return 0 on success and are called collectively, in the same order, by every rank.
+ * This is the stand-in for superlu_gridinit + SuperLU_DIST's internal MPI (src/solve_ABdist.c:461). */
+typedef struct nkp_comm_ops {
+   void *ctx;
+   int rank, nranks;
+   /* in-place reduction of `count` doubles in DEVICE memory; op 0 = sum, 1 = max; ordered on hip_stream */
+   int (*allreduce) (void *ctx, void *dev_buf, int count, int op, void *hip_stream);
+   /* personalised exchange of doubles in DEVICE memory: send_counts[p] values for rank p are taken
+    * consecutively from dev_send, recv_counts[p] values from rank p land consecutively in dev_recv */
+   int (*alltoallv) (void *ctx, const void *dev_send, const int *send_counts, void *dev_recv, const int *recv_counts, void *hip_stream);
+   /* setup only, HOST memory: the same exchange for int32, and an allgather of one int64 per rank */
+   int (*alltoallv_i32_host) (void *ctx, const int32_t *send, const int *send_counts, int32_t *recv, const int *recv_counts);
+   int (*allgather_i64_host) (void *ctx, int64_t mine, int64_t *all /* nranks */);
+} nkp_comm_ops;
+
 /* 128-byte RCCL unique id, created on rank 0 and broadcast by the caller (torch.distributed,
- * MPI or a shared file).  Replaces superlu_gridinit (src/solve_ABdist.c:461). */
+ * MPI or a shared file). */
 int nkp_comm_unique_id (void *id128);
+/* Fill `ops` with the built-in RCCL implementation (ncclCommInitRank on the current device). */
+int nkp_comm_rccl_init (nkp_comm_ops *ops, const void *id128, int rank, int nranks);
+void nkp_comm_rccl_free (nkp_comm_ops *ops);
 
 /* Local row block [fst_row, fst_row + m_loc) with GLOBAL column indices, rowptr rebased to 0
  * -- exactly what dCreate_CompRowLoc_Matrix_dist receives (src/solve_ABdist.c:482-483).
  * blk_start_loc holds the local block offsets (relative to fst_row, blk_start_loc[nblk_loc] =
- * m_loc); a water column must not straddle ranks.  Collective over all ranks. */
+ * m_loc); a water column must not straddle ranks.  Collective over all ranks.
+ * The Krylov iteration is global (halo exchange before every SpMV, one allreduce per
+ * Gram-Schmidt pass); the multilevel preconditioner is built from the rank's own diagonal block
+ * (non-overlapping Schwarz).  nkp_solve / nkp_solve_device then take and return the LOCAL slice
+ * of b / x, like pdgssvx with ldb = m_loc (src/solve_ABdist.c:571). */
 int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global, int64_t fst_row,
                      int64_t m_loc, int64_t nnz_loc, const int32_t *rowptr_loc,
                      const int32_t *colind_glob, const double *val,
                      const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt,
-                     int rank, int nranks, const void *id128);
+                     const nkp_comm_ops *comm);
+
+/* Host-only planning step of nkp_create_dist, exposed so the partition / halo logic can be tested
+ * without a GPU: given this rank's rows and the row offsets of all ranks (starts[nranks+1]),
+ * writes the remapped column indices (local rows -> [0, m_loc), halo -> m_loc + position in the
+ * sorted list of needed off-rank rows) into colind_ext[nnz_loc], the needed global rows into
+ * halo_rows (capacity nnz_loc; *n_halo entries used) and how many come from each rank into
+ * need_counts[nranks].  Returns 0 or NKP_EINVAL. */
+int nkp_dist_plan_host (int64_t m_loc, int64_t nnz_loc, const int32_t *rowptr_loc, const int32_t *colind_glob,
+                        int rank, int nranks, const int64_t *starts, int32_t *colind_ext, int32_t *halo_rows,
+                        int64_t *n_halo, int32_t *need_counts);
 
 #ifdef __cplusplus
 }

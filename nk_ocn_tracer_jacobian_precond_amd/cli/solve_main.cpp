@@ -240,8 +240,9 @@ int main (int argc, char *argv[])
    printf ("(%d) calling %s\n", iam, prog_solver);
    fflush (stdout);
 #ifdef NKP_DIST
+   // one rank owns every row: the reference's partition rule (src/solve_ABdist.c:141-144) with nprocs = 1
    int info = nkp_create_dist (&solver, &opt, flat_len, 0, flat_len, nnz, rowptr, colind, nzval_row_wise, blk_start, nblk,
-                               coupled_tracer_cnt, 0, 1, NULL);
+                               coupled_tracer_cnt, NULL);
 #else
    int info = nkp_create (&solver, &opt, flat_len, nnz, rowptr, colind, nzval_row_wise, blk_start, nblk, coupled_tracer_cnt);
 #endif

@@ -272,7 +272,7 @@ void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const d
 // runs its own short recurrence with the factors stored [diagonal][step k][lane] so that each
 // step is one coalesced 512-byte load per diagonal, and the result goes back coalesced.
 // 64x fewer wave-instructions per column; same operation order as the sequential kernel and
-// the oracle, so results are bit-identical.
+// the CPU restatement used by the tests, so results are bit-identical.
 #include <stdlib.h>
 #include <vector>
 

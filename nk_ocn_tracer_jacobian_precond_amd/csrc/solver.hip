@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -77,6 +78,16 @@ struct nkp_solver {
    CsrDev A;
    ColBlocksDev B;
    MlHierarchy ml;
+   // row-distributed flavour: halo exchange before every SpMV, allreduce after every local reduction
+   struct {
+      bool on = false;
+      nkp_comm_ops ops;
+      int64_t n_global = 0, fst = 0, n_halo = 0, nsend = 0;
+      std::vector<int> send_counts, recv_counts;
+      int *send_idx = nullptr;        // local rows other ranks need, grouped by destination rank
+      double *sendbuf = nullptr;      // packed values for them
+      double *xe = nullptr;           // [n + n_halo] extended SpMV input: own rows then halo rows
+   } dist;
    int64_t n = 0, ld = 0;
    int m = 0;
    // work vectors
@@ -112,6 +123,9 @@ static void solver_free (nkp_solver *s)
    for (void *p : ptrs)
       if (p) (void) hipFree (p);
    ml_free (s->ml);
+   if (s->dist.send_idx) (void) hipFree (s->dist.send_idx);
+   if (s->dist.sendbuf) (void) hipFree (s->dist.sendbuf);
+   if (s->dist.xe) (void) hipFree (s->dist.xe);
    if (s->hpin) (void) hipHostFree (s->hpin);
    if (s->own_stream && s->stream) (void) hipStreamDestroy (s->stream);
    delete s;
@@ -137,9 +151,38 @@ static void apply_precond (nkp_solver *s, const double *rin, double *zout)
    else launch_colblock_apply_lanes (s->B, 0, s->B.ngrp, rin, zout, 0, s->stream);
 }
 
-extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t n, int64_t nnz,
-                           const int32_t *rowptr, const int32_t *colind, const double *val,
-                           const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt)
+// y = A x (0), y = b - A x (1), y = |A||x| + |b| (2); in the distributed flavour the rows other
+// ranks own are fetched first (pack -> alltoallv -> extended input vector)
+static void spmv_op (nkp_solver *s, const double *x, double *y, const double *b, int mode)
+{
+   const double *xin = x;
+   if (s->dist.on) {
+      launch_copy (x, s->dist.xe, s->n, s->stream);
+      if (s->dist.nsend) launch_gather (s->dist.send_idx, x, s->dist.sendbuf, s->dist.nsend, s->stream);
+      (void) s->dist.ops.alltoallv (s->dist.ops.ctx, s->dist.sendbuf, s->dist.send_counts.data (), s->dist.xe + s->n,
+                                    s->dist.recv_counts.data (), (void *) s->stream);
+      xin = s->dist.xe;
+   }
+   if (mode == 2) launch_csr_abs_spmv (s->A, xin, b, y, s->stream);
+   else launch_csr_spmv (s->A, xin, y, b, mode, s->stream);
+}
+
+static inline void allreduce_dev (nkp_solver *s, double *dev, int count, int op)
+{
+   if (s->dist.on) (void) s->dist.ops.allreduce (s->dist.ops.ctx, dev, count, op, (void *) s->stream);
+}
+
+// the SpMV matrix (device copy; columns may address halo slots >= n) and the matrix the preconditioner
+// is built from (host only) are the same arrays except in the distributed flavour
+struct SpmvMatrixHost {
+   int64_t nnz, ncols;
+   const int32_t *rowptr, *colind;
+   const double *val;
+};
+
+static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, int64_t nnz,
+                        const int32_t *rowptr, const int32_t *colind, const double *val,
+                        const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt, const SpmvMatrixHost *spmv_mat)
 {
    if (!out) return fail (NKP_EINVAL, "nkp_create: out is NULL");
    *out = nullptr;
@@ -213,19 +256,21 @@ extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t 
    s->m = opt.restart;
 
    // matrix
+   const SpmvMatrixHost own = { nnz, n, rowptr, colind, val };
+   const SpmvMatrixHost &M = spmv_mat ? *spmv_mat : own;
    s->A.n = n;
-   s->A.nnz = nnz;
+   s->A.nnz = M.nnz;
    TRY (dev_alloc (s, &s->A.rowptr, (size_t) n + 1));
-   TRY (dev_alloc (s, &s->A.colind, (size_t) nnz));
-   TRY (dev_alloc (s, &s->A.val, (size_t) nnz));
-   TRYHIP (hipMemcpy (s->A.rowptr, rowptr, ((size_t) n + 1) * sizeof (int), hipMemcpyHostToDevice));
-   if (nnz) {
-      TRYHIP (hipMemcpy (s->A.colind, colind, (size_t) nnz * sizeof (int), hipMemcpyHostToDevice));
-      TRYHIP (hipMemcpy (s->A.val, val, (size_t) nnz * sizeof (double), hipMemcpyHostToDevice));
+   TRY (dev_alloc (s, &s->A.colind, (size_t) M.nnz));
+   TRY (dev_alloc (s, &s->A.val, (size_t) M.nnz));
+   TRYHIP (hipMemcpy (s->A.rowptr, M.rowptr, ((size_t) n + 1) * sizeof (int), hipMemcpyHostToDevice));
+   if (M.nnz) {
+      TRYHIP (hipMemcpy (s->A.colind, M.colind, (size_t) M.nnz * sizeof (int), hipMemcpyHostToDevice));
+      TRYHIP (hipMemcpy (s->A.val, M.val, (size_t) M.nnz * sizeof (double), hipMemcpyHostToDevice));
    }
    {
       int *rb = nullptr, nrb = 0;
-      build_rowblocks_host (n, rowptr, &rb, &nrb);
+      build_rowblocks_host (n, M.rowptr, &rb, &nrb);
       s->A.nrowblk = nrb;
       rc = dev_alloc (s, &s->A.rowblk, (size_t) nrb + 1);
       if (rc == NKP_OK && hipMemcpy (s->A.rowblk, rb, ((size_t) nrb + 1) * sizeof (int), hipMemcpyHostToDevice) != hipSuccess)
@@ -305,12 +350,19 @@ extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt_in, int64_t 
    }
    TRYHIP (hipStreamSynchronize (s->stream));
    TRYHIP (hipGetLastError ());
-   msg (s, 1, "nkp_create: n = %lld, nnz = %lld, %d SpMV row blocks, %.1f MB on device %d\n", (long long) n, (long long) nnz,
+   msg (s, 1, "nkp_create: n = %lld, nnz = %lld, %d SpMV row blocks, %.1f MB on device %d\n", (long long) n, (long long) M.nnz,
         s->A.nrowblk, (double) s->device_bytes / 1.0e6, s->device);
    *out = s;
    return NKP_OK;
 #undef TRY
 #undef TRYHIP
+}
+
+extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt, int64_t n, int64_t nnz,
+                           const int32_t *rowptr, const int32_t *colind, const double *val,
+                           const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt)
+{
+   return create_impl (out, opt, n, nnz, rowptr, colind, val, blk_start, nblk, coupled_tracer_cnt, nullptr);
 }
 
 extern "C" int nkp_set_stream (nkp_solver *s, void *hip_stream)
@@ -344,6 +396,7 @@ extern "C" int64_t nkp_get_int (nkp_solver *s, const char *key)
 static int dot_host (nkp_solver *s, const double *x, const double *y, double *out)
 {
    launch_dot (x, y, s->n, s->partial, s->misc_dev () + 2, s->stream);
+   allreduce_dev (s, s->misc_dev () + 2, 1, 0);
    HIPCHK (hipMemcpyAsync (s->hpin, s->misc_dev () + 2, sizeof (double), hipMemcpyDeviceToHost, s->stream));
    HIPCHK (hipStreamSynchronize (s->stream));
    *out = s->hpin[0];
@@ -357,15 +410,20 @@ static void arnoldi_step_device (nkp_solver *s, int j)
    const int64_t ld = s->ld;
    double *vj = s->V + (int64_t) j * ld, *zj = s->Z + (int64_t) j * ld;
    apply_precond (s, vj, zj);
-   launch_csr_spmv (s->A, zj, s->w, nullptr, 0, s->stream);
+   spmv_op (s, zj, s->w, nullptr, 0);
    launch_multi_dot (s->V, ld, j + 1, s->w, s->n, s->partial, s->h_dev (), s->stream);
+   allreduce_dev (s, s->h_dev (), j + 2, 0);                 // one allreduce per Gram-Schmidt pass
    launch_update_w (s->V, ld, j + 1, s->h_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
    if (s->opt.reorth) {
       launch_multi_dot (s->V, ld, j + 1, s->w, s->n, s->partial, s->h2_dev (), s->stream);
+      allreduce_dev (s, s->h2_dev (), j + 2, 0);
       launch_update_w (s->V, ld, j + 1, s->h2_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
+      allreduce_dev (s, s->misc_dev (), 1, 0);
       launch_finish_column (s->h_dev (), s->h2_dev (), j + 1, s->misc_dev (), s->misc_dev () + 1, s->stream);
-   } else
+   } else {
+      allreduce_dev (s, s->misc_dev (), 1, 0);
       launch_finish_column (s->h_dev (), nullptr, j + 1, s->misc_dev (), s->misc_dev () + 1, s->stream);
+   }
    launch_scale_to (s->w, s->misc_dev () + 1, s->V + (int64_t) (j + 1) * ld, s->n, s->stream);
 }
 
@@ -391,7 +449,7 @@ static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
    int status = NKP_NOT_CONVERGED;
    for (;;) {
       // true residual
-      launch_csr_spmv (s->A, s->x, s->r, s->b, 1, st);
+      spmv_op (s, s->x, s->r, s->b, 1);
       double r2 = 0.0;
       if ((rc = dot_host (s, s->r, s->r, &r2))) return rc;
       const double beta = sqrt (r2);
@@ -445,7 +503,7 @@ static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
       HIPCHK (hipStreamSynchronize (st));
       if (status == NKP_BREAKDOWN) {
          // report the true residual of what we have
-         launch_csr_spmv (s->A, s->x, s->r, s->b, 1, st);
+         spmv_op (s, s->x, s->r, s->b, 1);
          if ((rc = dot_host (s, s->r, s->r, &r2))) return rc;
          relres = sqrt (r2) / bnorm;
          if (sqrt (r2) <= target) status = NKP_OK;
@@ -472,7 +530,7 @@ static int bicgstab (nkp_solver *s, int *iters_out, double *relres_out)
    const double bnorm = sqrt (bnorm2);
    if (!(bnorm > 0.0)) { launch_fill (s->x, 0.0, n, st); *iters_out = 0; *relres_out = 0.0; return NKP_OK; }
    const double target = fmax (s->opt.rtol * bnorm, s->opt.atol);
-   launch_csr_spmv (s->A, s->x, r, s->b, 1, st);
+   spmv_op (s, s->x, r, s->b, 1);
    launch_copy (r, r0, n, st);
    launch_fill (p, 0.0, n, st);
    launch_fill (v, 0.0, n, st);
@@ -490,7 +548,7 @@ static int bicgstab (nkp_solver *s, int *iters_out, double *relres_out)
       launch_axpby (-omega, v, 1.0, p, n, st);
       launch_axpby (1.0, r, beta, p, n, st);
       apply_precond (s, p, ph);
-      launch_csr_spmv (s->A, ph, v, nullptr, 0, st);
+      spmv_op (s, ph, v, nullptr, 0);
       if ((rc = dot_host (s, r0, v, &tmp))) return rc;
       if (tmp == 0.0 || !(tmp == tmp)) { status = NKP_BREAKDOWN; break; }
       alpha = rho_new / tmp;
@@ -498,7 +556,7 @@ static int bicgstab (nkp_solver *s, int *iters_out, double *relres_out)
       launch_copy (r, sv, n, st);
       launch_axpby (-alpha, v, 1.0, sv, n, st);
       apply_precond (s, sv, sh);
-      launch_csr_spmv (s->A, sh, t, nullptr, 0, st);
+      spmv_op (s, sh, t, nullptr, 0);
       double ts, tt;
       if ((rc = dot_host (s, t, sv, &ts))) return rc;
       if ((rc = dot_host (s, t, t, &tt))) return rc;
@@ -517,7 +575,7 @@ static int bicgstab (nkp_solver *s, int *iters_out, double *relres_out)
       if (omega == 0.0) { status = NKP_BREAKDOWN; break; }
    }
    // true residual
-   launch_csr_spmv (s->A, s->x, r, s->b, 1, st);
+   spmv_op (s, s->x, r, s->b, 1);
    if ((rc = dot_host (s, r, r, &rn2))) return rc;
    relres = sqrt (rn2) / bnorm;
    if (sqrt (rn2) <= target * 1.0001) status = NKP_OK;
@@ -531,9 +589,10 @@ static int bicgstab (nkp_solver *s, int *iters_out, double *relres_out)
 // componentwise backward error of s->x for s->b, like SuperLU's berr
 static int backward_error (nkp_solver *s, double *berr)
 {
-   launch_csr_spmv (s->A, s->x, s->r, s->b, 1, s->stream);
-   launch_csr_abs_spmv (s->A, s->x, s->b, s->t1, s->stream);
+   spmv_op (s, s->x, s->r, s->b, 1);
+   spmv_op (s, s->x, s->t1, s->b, 2);
    launch_berr (s->r, s->t1, s->n, s->partial, s->misc_dev () + 3, s->stream);
+   allreduce_dev (s, s->misc_dev () + 3, 1, 1);
    HIPCHK (hipMemcpyAsync (s->hpin, s->misc_dev () + 3, sizeof (double), hipMemcpyDeviceToHost, s->stream));
    HIPCHK (hipStreamSynchronize (s->stream));
    *berr = s->hpin[0];
@@ -597,7 +656,7 @@ extern "C" int nkp_spmv_device (nkp_solver *s, const void *d_x, void *d_y)
 {
    if (!s || !d_x || !d_y) return fail (NKP_EINVAL, "nkp_spmv_device: NULL argument");
    HIPCHK (hipSetDevice (s->device));
-   launch_csr_spmv (s->A, (const double *) d_x, (double *) d_y, nullptr, 0, s->stream);
+   spmv_op (s, (const double *) d_x, (double *) d_y, nullptr, 0);
    HIPCHK (hipStreamSynchronize (s->stream));
    HIPCHK (hipGetLastError ());
    return NKP_OK;
@@ -609,7 +668,7 @@ extern "C" int nkp_spmv (nkp_solver *s, const double *x, double *y)
    HIPCHK (hipSetDevice (s->device));
    const size_t bytes = (size_t) s->n * sizeof (double);
    HIPCHK (hipMemcpyAsync (s->t1, x, bytes, hipMemcpyHostToDevice, s->stream));
-   launch_csr_spmv (s->A, s->t1, s->t2, nullptr, 0, s->stream);
+   spmv_op (s, s->t1, s->t2, nullptr, 0);
    HIPCHK (hipMemcpyAsync (y, s->t2, bytes, hipMemcpyDeviceToHost, s->stream));
    HIPCHK (hipStreamSynchronize (s->stream));
    HIPCHK (hipGetLastError ());
@@ -637,6 +696,7 @@ extern "C" int nkp_multi_dot (nkp_solver *s, const double *V, int64_t ld, int k,
       HIPCHK (hipMemcpyAsync (s->V + (int64_t) j * s->ld, V + (int64_t) j * ld, (size_t) s->n * sizeof (double), hipMemcpyHostToDevice, s->stream));
    HIPCHK (hipMemcpyAsync (s->w, w, (size_t) s->n * sizeof (double), hipMemcpyHostToDevice, s->stream));
    launch_multi_dot (s->V, s->ld, k, s->w, s->n, s->partial, s->h_dev (), s->stream);
+   allreduce_dev (s, s->h_dev (), k + 1, 0);
    HIPCHK (hipMemcpyAsync (out, s->h_dev (), (size_t) (k + 1) * sizeof (double), hipMemcpyDeviceToHost, s->stream));
    HIPCHK (hipStreamSynchronize (s->stream));
    HIPCHK (hipGetLastError ());
@@ -660,7 +720,7 @@ extern "C" int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, dou
       const int cnt = pass == 0 ? (reps < 3 ? reps : 3) : reps;
       HIPCHK (hipEventRecord (e0, s->stream));
       for (int i = 0; i < cnt; i++) {
-         if (which == 0) launch_csr_spmv (s->A, s->t1, s->t2, nullptr, 0, s->stream);
+         if (which == 0) spmv_op (s, s->t1, s->t2, nullptr, 0);
          else if (which == 1) apply_precond (s, s->t1, s->t2);
          else arnoldi_step_device (s, arg);
       }
@@ -676,21 +736,121 @@ extern "C" int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, dou
    return NKP_OK;
 }
 
-// ---------------------------------------------------------------- distributed flavour (next milestone)
-extern "C" int nkp_comm_unique_id (void *id128)
+// ---------------------------------------------------------------- distributed flavour
+extern "C" int nkp_dist_plan_host (int64_t m_loc, int64_t nnz_loc, const int32_t *rowptr_loc, const int32_t *colind_glob,
+                                   int rank, int nranks, const int64_t *starts, int32_t *colind_ext, int32_t *halo_rows,
+                                   int64_t *n_halo, int32_t *need_counts)
 {
-   (void) id128;
-   return fail (NKP_ECOMM, "nkp_comm_unique_id: the RCCL path is not built into this library yet");
+   if (!rowptr_loc || !starts || !colind_ext || !halo_rows || !n_halo || !need_counts || rank < 0 || rank >= nranks)
+      return fail (NKP_EINVAL, "nkp_dist_plan_host: bad argument");
+   if (nnz_loc > 0 && !colind_glob) return fail (NKP_EINVAL, "nkp_dist_plan_host: bad argument");
+   const int64_t fst = starts[rank], n_global = starts[nranks];
+   if (starts[rank + 1] - fst != m_loc || rowptr_loc[0] != 0 || rowptr_loc[m_loc] != nnz_loc)
+      return fail (NKP_EINVAL, "nkp_dist_plan_host: starts[] / rowptr_loc inconsistent with m_loc, nnz_loc");
+   // sorted unique off-rank columns
+   std::vector<int32_t> off;
+   for (int64_t e = 0; e < nnz_loc; e++) {
+      const int64_t c = colind_glob[e];
+      if (c < 0 || c >= n_global) return fail (NKP_EINVAL, "nkp_dist_plan_host: column index %lld out of range", (long long) c);
+      if (c < fst || c >= fst + m_loc) off.push_back ((int32_t) c);
+   }
+   std::sort (off.begin (), off.end ());
+   off.erase (std::unique (off.begin (), off.end ()), off.end ());
+   *n_halo = (int64_t) off.size ();
+   for (int p = 0; p < nranks; p++) need_counts[p] = 0;
+   {
+      int p = 0;
+      for (size_t q = 0; q < off.size (); q++) {
+         while (off[q] >= starts[p + 1]) p++;           // sorted rows, ascending owners
+         need_counts[p]++;
+         halo_rows[q] = off[q];
+      }
+   }
+   for (int64_t e = 0; e < nnz_loc; e++) {
+      const int64_t c = colind_glob[e];
+      if (c >= fst && c < fst + m_loc) colind_ext[e] = (int32_t) (c - fst);
+      else colind_ext[e] = (int32_t) (m_loc + (std::lower_bound (off.begin (), off.end (), (int32_t) c) - off.begin ()));
+   }
+   return NKP_OK;
 }
 
 extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global, int64_t fst_row, int64_t m_loc,
                                 int64_t nnz_loc, const int32_t *rowptr_loc, const int32_t *colind_glob, const double *val,
-                                const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt, int rank, int nranks,
-                                const void *id128)
+                                const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt, const nkp_comm_ops *comm)
 {
-   (void) id128;
-   if (nranks == 1 && fst_row == 0 && m_loc == n_global)
-      return nkp_create (out, opt, n_global, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt);
-   (void) rank;
-   return fail (NKP_ECOMM, "nkp_create_dist: multi-rank solves are not built into this library yet");
+   if (!out) return fail (NKP_EINVAL, "nkp_create_dist: out is NULL");
+   *out = nullptr;
+   if (!comm || comm->nranks <= 1) {
+      if (fst_row != 0 || m_loc != n_global) return fail (NKP_EINVAL, "nkp_create_dist: a single rank must own all rows");
+      return create_impl (out, opt, n_global, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt, nullptr);
+   }
+   if (!comm->allreduce || !comm->alltoallv || !comm->alltoallv_i32_host || !comm->allgather_i64_host)
+      return fail (NKP_EINVAL, "nkp_create_dist: incomplete nkp_comm_ops");
+   if (!rowptr_loc || m_loc < 0 || nnz_loc < 0 || (nnz_loc > 0 && (!colind_glob || !val))) return fail (NKP_EINVAL, "nkp_create_dist: bad matrix arguments");
+   const int P = comm->nranks, rank = comm->rank;
+   std::vector<int64_t> starts (P + 1, 0);
+   if (comm->allgather_i64_host (comm->ctx, fst_row, starts.data ())) return fail (NKP_ECOMM, "nkp_create_dist: allgather failed");
+   starts[P] = n_global;
+   for (int p = 0; p < P; p++)
+      if (starts[p + 1] < starts[p] || starts[0] != 0) return fail (NKP_EINVAL, "nkp_create_dist: row blocks must be contiguous and ascending over the ranks");
+   if (starts[rank + 1] - starts[rank] != m_loc) return fail (NKP_EINVAL, "nkp_create_dist: m_loc does not match the next rank's fst_row");
+
+   std::vector<int32_t> colind_ext ((size_t) nnz_loc + 1), halo_rows ((size_t) nnz_loc + 1), need (P), give (P), ones (P, 1);
+   int64_t n_halo = 0;
+   int rc = nkp_dist_plan_host (m_loc, nnz_loc, rowptr_loc, colind_glob, rank, P, starts.data (), colind_ext.data (), halo_rows.data (), &n_halo, need.data ());
+   if (rc) return rc;
+   // tell every owner how many and which of its rows this rank reads
+   if (comm->alltoallv_i32_host (comm->ctx, need.data (), ones.data (), give.data (), ones.data ())) return fail (NKP_ECOMM, "nkp_create_dist: count exchange failed");
+   int64_t nsend = 0;
+   for (int p = 0; p < P; p++) nsend += give[p];
+   std::vector<int32_t> send_rows ((size_t) nsend + 1);
+   if (comm->alltoallv_i32_host (comm->ctx, halo_rows.data (), need.data (), send_rows.data (), give.data ())) return fail (NKP_ECOMM, "nkp_create_dist: index exchange failed");
+   for (int64_t q = 0; q < nsend; q++) {
+      send_rows[q] -= (int32_t) fst_row;
+      if (send_rows[q] < 0 || send_rows[q] >= m_loc) return fail (NKP_ECOMM, "nkp_create_dist: a peer asked for a row this rank does not own");
+   }
+   // diagonal block for the rank-local preconditioner
+   std::vector<int32_t> drow ((size_t) m_loc + 1, 0), dcol;
+   std::vector<double> dval;
+   dcol.reserve ((size_t) nnz_loc);
+   dval.reserve ((size_t) nnz_loc);
+   for (int64_t r = 0; r < m_loc; r++) {
+      for (int e = rowptr_loc[r]; e < rowptr_loc[r + 1]; e++)
+         if (colind_ext[e] < m_loc) { dcol.push_back (colind_ext[e]); dval.push_back (val[e]); }
+      drow[r + 1] = (int32_t) dcol.size ();
+   }
+   SpmvMatrixHost M = { nnz_loc, m_loc + n_halo, rowptr_loc, colind_ext.data (), val };
+   nkp_options o;
+   if (opt) o = *opt;
+   else nkp_default_options (&o);
+   o.rank = rank;
+   nkp_solver *s = nullptr;
+   rc = create_impl (&s, &o, m_loc, (int64_t) dcol.size (), drow.data (), dcol.data (), dval.data (), blk_start_loc, nblk_loc, coupled_tracer_cnt, &M);
+   // every rank must reach the collectives below even if its own setup failed: agree on success first
+   {
+      int64_t flag = rc ? 1 : 0;
+      std::vector<int64_t> all (P + 1, 0);
+      if (comm->allgather_i64_host (comm->ctx, flag, all.data ())) { if (s) solver_free (s); return fail (NKP_ECOMM, "nkp_create_dist: allgather failed"); }
+      for (int p = 0; p < P; p++)
+         if (all[p]) {
+            if (s) solver_free (s);
+            return rc ? rc : fail (NKP_ECOMM, "nkp_create_dist: setup failed on rank %d", p);
+         }
+   }
+   s->dist.ops = *comm;
+   s->dist.n_global = n_global;
+   s->dist.fst = fst_row;
+   s->dist.n_halo = n_halo;
+   s->dist.nsend = nsend;
+   s->dist.send_counts.assign (give.begin (), give.end ());
+   s->dist.recv_counts.assign (need.begin (), need.end ());
+   bool ok = dev_alloc (s, &s->dist.send_idx, (size_t) nsend) == NKP_OK && dev_alloc (s, &s->dist.sendbuf, (size_t) nsend) == NKP_OK &&
+             dev_alloc (s, &s->dist.xe, (size_t) (m_loc + n_halo)) == NKP_OK;
+   if (ok && nsend) ok = hipMemcpy (s->dist.send_idx, send_rows.data (), (size_t) nsend * sizeof (int), hipMemcpyHostToDevice) == hipSuccess;
+   if (!ok) { solver_free (s); return fail (NKP_ENOMEM, "nkp_create_dist: halo buffers could not be allocated"); }
+   s->dist.on = true;
+   msg (s, 1, "nkp_create_dist: rows [%lld, %lld) of %lld, %lld halo rows in, %lld rows out\n", (long long) fst_row,
+        (long long) (fst_row + m_loc), (long long) n_global, (long long) n_halo, (long long) nsend);
+   *out = s;
+   return NKP_OK;
 }

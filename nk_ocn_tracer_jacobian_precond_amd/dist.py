@@ -1,0 +1,199 @@
+"""Row-distributed flavour (one process per GPU): partition helpers, a torch.distributed-backed
+implementation of the four collectives the C library needs (include/nkp.h `nkp_comm_ops`), and the
+NkpDistSolver wrapper around nkp_create_dist.
+
+Mirrors the reference's distributed executable (src/solve_ABdist.c): contiguous row blocks
+(:141-144, snapped here to water-column boundaries so that a column never straddles ranks),
+local rowptr rebased to 0 with GLOBAL column indices (:170-175, 188-225).
+
+backend "nccl" (= RCCL on ROCm): the collectives act directly on the library's device buffers.
+backend "gloo": the same calls staged through host memory (CPU tests; 2 ranks sharing one GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import solver as _solver
+
+
+def snap_partition(blk_start, nranks):
+    """Row offsets starts[nranks+1]: the reference's n/P split, each cut moved to the nearest
+    water-column boundary."""
+    blk_start = np.asarray(blk_start, np.int64)
+    n = int(blk_start[-1])
+    starts = [0]
+    for r in range(1, nranks):
+        target = r * (n // nranks)
+        q = int(np.searchsorted(blk_start, target))
+        cand = [blk_start[max(q - 1, 0)], blk_start[min(q, blk_start.size - 1)]]
+        cut = int(min(cand, key=lambda c: abs(int(c) - target)))
+        starts.append(max(cut, starts[-1]))
+    starts.append(n)
+    return np.asarray(starts, np.int64)
+
+
+def local_slice(rowptr, colind, val, blk_start, starts, rank, col_i=None, col_j=None):
+    """This rank's rows: rebased rowptr, GLOBAL colind, values, local block offsets (+ coords)."""
+    f, e = int(starts[rank]), int(starts[rank + 1])
+    rp = np.asarray(rowptr[f:e + 1], np.int64)
+    lo, hi = int(rp[0]), int(rp[-1])
+    blk_start = np.asarray(blk_start, np.int64)
+    b0, b1 = int(np.searchsorted(blk_start, f)), int(np.searchsorted(blk_start, e))
+    if blk_start[b0] != f or blk_start[b1] != e:
+        raise ValueError("partition cuts a water column")
+    out = dict(rowptr=(rp - lo).astype(np.int32), colind=np.ascontiguousarray(colind[lo:hi], np.int32),
+               val=np.ascontiguousarray(val[lo:hi], np.float64), blk_start=(blk_start[b0:b1 + 1] - f).astype(np.int32),
+               fst_row=f, m_loc=e - f)
+    if col_i is not None:
+        out["col_i"] = np.ascontiguousarray(col_i[b0:b1], np.int32)
+        out["col_j"] = np.ascontiguousarray(col_j[b0:b1], np.int32)
+    return out
+
+
+def plan_host(rowptr_loc, colind_glob, starts, rank):
+    """nkp_dist_plan_host: remapped columns, needed off-rank rows, per-owner counts (no GPU needed)."""
+    lib = _solver.load_library()
+    rp = np.ascontiguousarray(rowptr_loc, np.int32)
+    ci = np.ascontiguousarray(colind_glob, np.int32)
+    st = np.ascontiguousarray(starts, np.int64)
+    P = st.size - 1
+    ext = np.empty(max(ci.size, 1), np.int32)
+    halo = np.empty(max(ci.size, 1), np.int32)
+    need = np.zeros(P, np.int32)
+    nh = C.c_int64()
+    rc = lib.nkp_dist_plan_host(rp.size - 1, ci.size, rp.ctypes.data_as(C.POINTER(C.c_int32)), ci.ctypes.data_as(C.POINTER(C.c_int32)),
+                                rank, P, st.ctypes.data_as(C.POINTER(C.c_int64)), ext.ctypes.data_as(C.POINTER(C.c_int32)),
+                                halo.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nh), need.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc:
+        raise _solver.NkpError(rc, lib.nkp_last_error().decode())
+    return ext[:ci.size], halo[:nh.value].copy(), need
+
+
+class _DevArray:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr=typestr, data=(int(ptr), False), version=3)
+
+
+class TorchComm:
+    """nkp_comm_ops on top of an initialised torch.distributed process group."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+        self.device_native = dist.get_backend() == "nccl"
+        self.errors = []
+        self._fns = (_solver._ALLREDUCE_FN(self._allreduce), _solver._ALLTOALLV_FN(self._alltoallv),
+                     _solver._ALLTOALLV_I32_FN(self._alltoallv_i32_host), _solver._ALLGATHER_I64_FN(self._allgather_i64_host))
+        self.ops = _solver.NkpCommOps(None, self.rank, self.nranks, *self._fns)
+
+    # ---- helpers
+    def _dev(self, ptr, n):
+        return self.torch.as_tensor(_DevArray(ptr, n, "<f8"), device="cuda")
+
+    def _exchange_host(self, send, scnt, recv, rcnt):
+        """alltoallv of 1-D CPU tensors with isend/irecv (gloo has no all_to_all)."""
+        dist = self.dist
+        so = np.concatenate([[0], np.cumsum(scnt)]).astype(np.int64)
+        ro = np.concatenate([[0], np.cumsum(rcnt)]).astype(np.int64)
+        reqs = []
+        for p in range(self.nranks):
+            if p == self.rank:
+                if scnt[p]:
+                    recv[ro[p]:ro[p + 1]] = send[so[p]:so[p + 1]]
+                continue
+            if rcnt[p]:
+                reqs.append(dist.irecv(recv[ro[p]:ro[p + 1]], src=p))
+            if scnt[p]:
+                reqs.append(dist.isend(send[so[p]:so[p + 1]].contiguous(), dst=p))
+        for r in reqs:
+            r.wait()
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as exc:                      # never let an exception cross the C boundary
+            self.errors.append(repr(exc))
+            return 1
+
+    # ---- the four collectives
+    def _allreduce(self, ctx, dev_buf, count, op, stream):
+        def run():
+            t = self._dev(dev_buf, count)
+            rop = self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM
+            if self.device_native:
+                self.dist.all_reduce(t, op=rop)
+            else:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=rop)
+                t.copy_(h)
+        return self._guard(run)
+
+    def _alltoallv(self, ctx, dev_send, scnt, dev_recv, rcnt, stream):
+        def run():
+            sc = [int(scnt[p]) for p in range(self.nranks)]
+            rc = [int(rcnt[p]) for p in range(self.nranks)]
+            ns, nr = sum(sc), sum(rc)
+            send = self._dev(dev_send, ns) if ns else self.torch.empty(0, dtype=self.torch.float64, device="cuda")
+            recv = self._dev(dev_recv, nr) if nr else self.torch.empty(0, dtype=self.torch.float64, device="cuda")
+            if self.device_native:
+                self.dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
+            else:
+                hs, hr = send.cpu(), self.torch.empty(nr, dtype=self.torch.float64)
+                self._exchange_host(hs, sc, hr, rc)
+                if nr:
+                    recv.copy_(hr)
+        return self._guard(run)
+
+    def _alltoallv_i32_host(self, ctx, send, scnt, recv, rcnt):
+        def run():
+            torch = self.torch
+            sc = [int(scnt[p]) for p in range(self.nranks)]
+            rc = [int(rcnt[p]) for p in range(self.nranks)]
+            ns, nr = sum(sc), sum(rc)
+            hs = torch.from_numpy(np.ctypeslib.as_array(send, (max(ns, 1),))[:ns].copy())
+            hr = torch.empty(nr, dtype=torch.int32)
+            if self.device_native:
+                ds, dr = hs.cuda(), torch.empty(nr, dtype=torch.int32, device="cuda")
+                self.dist.all_to_all_single(dr, ds, output_split_sizes=rc, input_split_sizes=sc)
+                hr = dr.cpu()
+            else:
+                self._exchange_host(hs, sc, hr, rc)
+            if nr:
+                np.ctypeslib.as_array(recv, (nr,))[:] = hr.numpy()
+        return self._guard(run)
+
+    def _allgather_i64_host(self, ctx, mine, out):
+        def run():
+            torch = self.torch
+            dev = "cuda" if self.device_native else "cpu"
+            t = torch.tensor([int(mine)], dtype=torch.int64, device=dev)
+            parts = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(self.nranks)]
+            self.dist.all_gather(parts, t)
+            for p in range(self.nranks):
+                out[p] = int(parts[p].item())
+        return self._guard(run)
+
+
+class NkpDistSolver(_solver.NkpSolver):
+    """nkp_create_dist: this rank's row block in, a solver for the LOCAL slices of b / x out."""
+
+    def __init__(self, loc, n_global, comm, coupled_tracer_cnt=1, **options):
+        lib = _solver.load_library()
+        self._comm = comm                      # keeps the callbacks alive
+        opt = _solver.default_options(**options)
+        rp, ci, v, bs = loc["rowptr"], loc["colind"], loc["val"], loc["blk_start"]
+        self._keep = (rp, ci, v, bs, loc.get("col_i"), loc.get("col_j"))
+        if loc.get("col_i") is not None:
+            opt.col_i, opt.col_j = _solver._p(loc["col_i"], C.c_int32), _solver._p(loc["col_j"], C.c_int32)
+        h = C.c_void_p()
+        rc = lib.nkp_create_dist(C.byref(h), C.byref(opt), int(n_global), int(loc["fst_row"]), int(loc["m_loc"]), int(ci.size),
+                                 _solver._p(rp, C.c_int32), _solver._p(ci, C.c_int32), _solver._p(v, C.c_double),
+                                 _solver._p(bs, C.c_int32), int(bs.size - 1), coupled_tracer_cnt, C.byref(comm.ops))
+        if rc != 0:
+            raise _solver.NkpError(rc, lib.nkp_last_error().decode() + (" | comm: " + "; ".join(comm.errors) if comm.errors else ""))
+        self._lib, self._h, self.n, self.nnz, self.options = lib, h, int(loc["m_loc"]), int(ci.size), opt

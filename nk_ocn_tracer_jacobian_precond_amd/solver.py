@@ -25,8 +25,19 @@ ABI_SYMBOLS = [
     "nkp_default_options", "nkp_device_count", "nkp_create", "nkp_solve", "nkp_solve_device",
     "nkp_spmv", "nkp_spmv_device", "nkp_precond_apply", "nkp_multi_dot", "nkp_time_kernel",
     "nkp_get_int", "nkp_set_stream", "nkp_destroy", "nkp_last_error", "nkp_comm_unique_id",
-    "nkp_create_dist",
+    "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host",
 ]
+
+_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
+_ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int), C.c_void_p)
+_ALLTOALLV_I32_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_int32), C.POINTER(C.c_int))
+_ALLGATHER_I64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64))
+
+
+class NkpCommOps(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int), ("allreduce", _ALLREDUCE_FN),
+                ("alltoallv", _ALLTOALLV_FN), ("alltoallv_i32_host", _ALLTOALLV_I32_FN),
+                ("allgather_i64_host", _ALLGATHER_I64_FN)]
 
 
 class NkpOptions(C.Structure):
@@ -77,8 +88,13 @@ def load_library(path=None):
     lib.nkp_destroy.restype = None
     lib.nkp_last_error.restype = C.c_char_p
     lib.nkp_comm_unique_id.argtypes = [vp]
+    lib.nkp_comm_rccl_init.argtypes = [C.POINTER(NkpCommOps), vp, C.c_int, C.c_int]
+    lib.nkp_comm_rccl_free.argtypes = [C.POINTER(NkpCommOps)]
+    lib.nkp_comm_rccl_free.restype = None
     lib.nkp_create_dist.argtypes = [C.POINTER(vp), C.POINTER(NkpOptions), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
-                                    i32p, i32p, f64p, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, vp]
+                                    i32p, i32p, f64p, i32p, C.c_int64, C.c_int, C.POINTER(NkpCommOps)]
+    lib.nkp_dist_plan_host.argtypes = [C.c_int64, C.c_int64, i32p, i32p, C.c_int, C.c_int, C.POINTER(C.c_int64), i32p, i32p,
+                                       C.POINTER(C.c_int64), i32p]
     if path == HIP_LIB_PATH:
         _lib = lib
     return lib
@@ -128,6 +144,12 @@ class NkpSolver:
         if rc != 0:
             self._h = C.c_void_p()
             raise NkpError(rc, self._lib.nkp_last_error().decode())
+
+    @classmethod
+    def _from_handle(cls, lib, handle, n, nnz, options):
+        self = cls.__new__(cls)
+        self._lib, self._h, self.n, self.nnz, self.options = lib, handle, n, nnz, options
+        return self
 
     def _check(self, rc, allow=(0,)):
         if rc not in allow:

@@ -1,0 +1,89 @@
+"""Worker for the multi-process tests (launched once per rank by tests/test_dist_*.py).
+
+  --mode cpu-plan   gloo on CPU: halo plan + index/value exchange, distributed SpMV == global SpMV
+  --mode gpu-solve  gloo + host staging, all ranks share the one GPU: distributed solve of A x = b
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--grid", default="24x20x10")
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_binding as ora
+    from nk_ocn_tracer_jacobian_precond_amd import dist as nd
+    from nk_ocn_tracer_jacobian_precond_amd import solver, synth
+
+    imt, jmt, km = (int(t) for t in a.grid.split("x"))
+    p = synth.generate(imt=imt, jmt=jmt, km=km, adv="upwind3", hmix="isop", seed=5)
+    n = p.flat_len
+    blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    starts = nd.snap_partition(blk, world)
+    loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, rank, ci, cj)
+    f, m = loc["fst_row"], loc["m_loc"]
+    rng = np.random.default_rng(3)
+    xg = rng.standard_normal(n)
+    comm = nd.TorchComm()
+    result = dict(rank=rank, m_loc=m)
+
+    if a.mode == "cpu-plan":
+        ext, halo, need = nd.plan_host(loc["rowptr"], loc["colind"], starts, rank)
+        give = torch.empty(world, dtype=torch.int32)
+        comm._exchange_host(torch.from_numpy(need.copy()), [1] * world, give, [1] * world)
+        give = give.numpy()
+        send_rows = torch.empty(int(give.sum()), dtype=torch.int32)
+        comm._exchange_host(torch.from_numpy(halo.copy()), need.tolist(), send_rows, give.tolist())
+        send_rows = send_rows.numpy().astype(np.int64) - f
+        assert send_rows.min(initial=0) >= 0 and send_rows.max(initial=0) < max(m, 1)
+        x_loc = xg[f:f + m]
+        recv = torch.empty(int(need.sum()), dtype=torch.float64)
+        comm._exchange_host(torch.from_numpy(x_loc[send_rows].copy()), give.tolist(), recv, need.tolist())
+        assert np.array_equal(recv.numpy(), xg[halo])                     # the halo holds the right rows
+        x_ext = np.concatenate([x_loc, recv.numpy()])
+        y_loc = ora.spmv(loc["rowptr"], ext, loc["val"], x_ext)
+        y_ref = ora.spmv(p.rowptr, p.colind, p.nzval, xg)[f:f + m]
+        result["spmv_bit_exact"] = bool(np.array_equal(y_loc, y_ref))
+        result["n_halo"] = int(halo.size)
+        result["neighbours"] = int((need > 0).sum())
+    else:
+        torch.cuda.set_device(0)
+        b = rng.standard_normal(n)
+        s = nd.NkpDistSolver(loc, n, comm, rtol=1e-10, restart=60, max_iters=3000)
+        s.set_stream(torch.cuda.current_stream().cuda_stream)
+        y_loc = s.spmv(xg[f:f + m])
+        y_ref = ora.spmv(p.rowptr, p.colind, p.nzval, xg)[f:f + m]
+        result["spmv_bit_exact"] = bool(np.array_equal(y_loc, y_ref))
+        x_loc, info = s.solve(b[f:f + m], raise_on_fail=False)
+        result.update(info)
+        parts = [torch.empty(int(starts[r + 1] - starts[r]), dtype=torch.float64) for r in range(world)] if rank == 0 else None
+        dist.gather(torch.from_numpy(x_loc.copy()), parts, dst=0)
+        if rank == 0:
+            x = np.concatenate([t.numpy() for t in parts])
+            r = b - ora.spmv(p.rowptr, p.colind, p.nzval, x)
+            result["relres_checked"] = float(np.linalg.norm(r) / np.linalg.norm(b))
+        result["comm_errors"] = comm.errors
+        s.close()
+    with open(f"{a.out}.{rank}", "w") as fh:
+        json.dump(result, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
