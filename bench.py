@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--max-iters", type=int, default=20000)
     ap.add_argument("--cpu-baseline-iters", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="developer switch: run the distributed code path even with one rank")
     return ap.parse_args()
 
 
@@ -80,10 +81,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the solve path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if a.force_dist:
+        os.environ["NKP_FORCE_DIST"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29511")
+    if world > 1 or a.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    from nk_ocn_tracer_jacobian_precond_amd import dist as nd
     from nk_ocn_tracer_jacobian_precond_amd import solver, synth
 
     imt, jmt, km = (int(t) for t in a.grid.split("x"))
@@ -93,23 +98,54 @@ def main():
     ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    s = solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, device=local_rank,
-                         precond=solver.PRECOND_MULTILEVEL, restart=a.restart, ml_smooth=a.ml_smooth, rtol=a.rtol,
-                         max_iters=a.max_iters, rank=rank)
+    kw = dict(device=local_rank, precond=solver.PRECOND_MULTILEVEL, restart=a.restart, ml_smooth=a.ml_smooth, rtol=a.rtol,
+              max_iters=a.max_iters, rank=rank)
+    n_global = p.flat_len
+    mode = "single GPU"
+    fst = 0
+    if world > 1 or a.force_dist:
+        # strong scaling: the SAME 1 degree matrix, rows split into `world` latitude bands (the reference's
+        # rule, src/solve_ABdist.c:141-144, cuts snapped to water-column boundaries); halo exchange +
+        # allreduce through torch.distributed's RCCL communicator, rank-local multilevel preconditioner
+        try:
+            starts = nd.snap_partition(blk, world)
+            loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, rank, ci, cj)
+            comm = nd.TorchComm()
+            s = nd.NkpDistSolver(loc, n_global, comm, **kw)
+            s.set_stream(torch.cuda.current_stream().cuda_stream)
+            fst = loc["fst_row"]
+            mode = f"rows split into {world} latitude bands, halo alltoallv + allreduce over RCCL (torch.distributed), rank-local multilevel preconditioner"
+        except Exception as exc:                           # keep the scaling run alive, but say what happened
+            print(f"({rank}) distributed setup failed, falling back to one replica per rank: {exc!r}", file=sys.stderr)
+            s = None
+        ok = torch.tensor([1 if s is not None else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            s = None
+            mode = "FALLBACK: one replica of the solve per rank (distributed setup failed, see stderr)"
+    if (world == 1 and not a.force_dist) or s is None:
+        s = solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, **kw)
+    distributed = (world > 1 or a.force_dist) and not mode.startswith("FALLBACK")
     t_setup = time.perf_counter() - t0
-    n = p.flat_len
+    n = s.n                                               # rows this rank solves for
 
     # right-hand sides resident in HBM before the timed region
     gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
+    gen.manual_seed(1234 if distributed else 1234 + rank)
     nrhs = a.warmup + a.steps
-    B = torch.randn((nrhs, n), dtype=torch.float64, device="cuda", generator=gen)
+    if distributed:                                       # every rank draws the same global rhs and keeps its slice
+        B = torch.stack([torch.randn(n_global, dtype=torch.float64, device="cuda", generator=gen)[fst:fst + n] for _ in range(nrhs)])
+    else:
+        B = torch.randn((nrhs, n), dtype=torch.float64, device="cuda", generator=gen)
     X = torch.zeros((nrhs, n), dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
+
+    if world > 1 or a.force_dist:
+        a.no_cpu_baseline = a.no_cpu_baseline or world > 1     # the CPU leg is an N = 1 measurement
 
     infos = []
     for k in range(a.warmup):
@@ -127,14 +163,32 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # independent check of the last solution with torch (not the kernel under test)
-    crow = torch.from_numpy(p.rowptr.astype(np.int64)).cuda()
-    ccol = torch.from_numpy(p.colind.astype(np.int64)).cuda()
-    cval = torch.from_numpy(p.nzval).cuda()
-    At = torch.sparse_csr_tensor(crow, ccol, cval, size=(n, n))
-    r = B[-1] - (At @ X[-1].unsqueeze(1)).squeeze(1)
-    relres_check = float(torch.linalg.norm(r) / torch.linalg.norm(B[-1]))
-    del At, crow, ccol, cval
+    # independent check of the last solution with torch's own SpMV (not the kernel under test)
+    relres_check = None
+    try:
+        if distributed:
+            sizes = [int(starts[r + 1] - starts[r]) for r in range(world)]
+            pad = max(sizes)
+
+            def gather_padded(v):                          # equal-size all_gather, then trim
+                mine = torch.zeros(pad, dtype=torch.float64, device="cuda")
+                mine[:v.numel()] = v
+                parts = [torch.empty(pad, dtype=torch.float64, device="cuda") for _ in range(world)]
+                dist.all_gather(parts, mine)
+                return torch.cat([parts[r][:sizes[r]] for r in range(world)])
+            xg, bg = gather_padded(X[-1]), gather_padded(B[-1])
+        else:
+            xg, bg = X[-1], B[-1]
+        if rank == 0:
+            crow = torch.from_numpy(p.rowptr.astype(np.int64)).cuda()
+            ccol = torch.from_numpy(p.colind.astype(np.int64)).cuda()
+            cval = torch.from_numpy(p.nzval).cuda()
+            At = torch.sparse_csr_tensor(crow, ccol, cval, size=(n_global, n_global))
+            r = bg - (At @ xg.unsqueeze(1)).squeeze(1)
+            relres_check = float(torch.linalg.norm(r) / torch.linalg.norm(bg))
+            del At, crow, ccol, cval
+    except Exception as exc:
+        print(f"({rank}) residual re-check skipped: {exc!r}", file=sys.stderr)
 
     # dominant-kernel roofline: the CSR SpMV, timed with HIP events on the solver's own stream
     spmv_ms = s.time_kernel(0, reps=200)
@@ -144,28 +198,27 @@ def main():
     it_ms = {f"j{j}": s.time_kernel(2, reps=10, arg=j) for j in (0, a.restart // 2, a.restart - 1)}
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     iters = [i["iters"] for i in infos]
     out = {
         "metric": "precond_solve_throughput_1deg_ocean_jacobian",
-        "value": world * a.steps * n / dt,
+        "value": (1 if distributed else world) * a.steps * n_global / dt,
         "unit": "unknowns/s",
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if distributed else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": f"{a.grid} ({'1' if imt == 320 else '?'} degree x {km} level) single-tracer ocean Jacobian, "
-                        f"adv={a.adv} hmix={a.hmix}, n={n}, nnz={p.nnz}; FGMRES({a.restart}) + multilevel water-column "
+                        f"adv={a.adv} hmix={a.hmix}, n={n_global}, nnz={p.nnz}; FGMRES({a.restart}) + multilevel water-column "
                         f"preconditioner V({a.ml_smooth},{a.ml_smooth}), rtol={a.rtol:g}; one solve per step, rhs resident in HBM",
-            "multi_gpu": "one replica of the solve per rank (the row-partitioned RCCL path is not built yet)" if world > 1 else "single GPU",
+            "multi_gpu": mode,
         },
         "solve": {"iterations": iters, "relres": [i["relres"] for i in infos], "berr": [i["berr"] for i in infos],
                   "relres_checked_with_torch": relres_check, "setup_s": t_setup, "generate_s": t_gen,
@@ -178,7 +231,7 @@ def main():
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(p, blk, int(round(float(np.mean(iters)))), a.cpu_baseline_iters)
     print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

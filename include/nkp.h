@@ -131,7 +131,8 @@ int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, double *avg_ms
 /* Introspection: key = "n", "nnz", "nblk", "band", "levels", "spmv_bytes", "device_bytes". */
 int64_t nkp_get_int (nkp_solver *s, const char *key);
 
-/* Use an externally owned HIP stream (hipStream_t cast to void*); NULL = the solver's own. */
+/* Use an externally owned HIP stream (hipStream_t cast to void*) instead of the solver's own;
+ * NULL = the device's default stream. */
 int nkp_set_stream (nkp_solver *s, void *hip_stream);
 
 void nkp_destroy (nkp_solver *s);

@@ -369,8 +369,10 @@ extern "C" int nkp_set_stream (nkp_solver *s, void *hip_stream)
 {
    if (!s) return fail (NKP_EINVAL, "nkp_set_stream: NULL solver");
    if (s->own_stream && s->stream) { (void) hipStreamSynchronize (s->stream); (void) hipStreamDestroy (s->stream); }
-   if (hip_stream) { s->stream = (hipStream_t) hip_stream; s->own_stream = false; }
-   else { HIPCHK (hipStreamCreateWithFlags (&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+   // NULL is a stream too: the device's default stream (what torch.cuda.current_stream() is unless the
+   // caller switched streams), so work enqueued here stays ordered with the caller's own kernels
+   s->stream = (hipStream_t) hip_stream;
+   s->own_stream = false;
    return NKP_OK;
 }
 
@@ -780,7 +782,7 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
 {
    if (!out) return fail (NKP_EINVAL, "nkp_create_dist: out is NULL");
    *out = nullptr;
-   if (!comm || comm->nranks <= 1) {
+   if (!comm || (comm->nranks <= 1 && !getenv ("NKP_FORCE_DIST"))) {
       if (fst_row != 0 || m_loc != n_global) return fail (NKP_EINVAL, "nkp_create_dist: a single rank must own all rows");
       return create_impl (out, opt, n_global, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt, nullptr);
    }
