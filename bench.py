@@ -36,8 +36,8 @@ def parse():
     ap.add_argument("--grid", default="320x384x60")
     ap.add_argument("--adv", default="upwind3")
     ap.add_argument("--hmix", default="isop")
-    ap.add_argument("--restart", type=int, default=100)
-    ap.add_argument("--ml-smooth", type=int, default=2)
+    ap.add_argument("--restart", type=int, default=200)
+    ap.add_argument("--ml-smooth", type=int, default=3)
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--max-iters", type=int, default=20000)
     ap.add_argument("--cpu-baseline-iters", type=int, default=100)

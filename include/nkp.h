@@ -73,7 +73,7 @@ typedef struct nkp_options {
    int device;           /* HIP device ordinal; -1 = leave the current device                 */
    int verbose;          /* the reference's dbg_lvl: 0 silent, 1 progress, 2 per-iteration    */
    int rank;             /* printed as the "(rank)" message prefix (reference `iam`)          */
-   int reorth;           /* 0 = one classical Gram-Schmidt pass, 1 = two passes (default)     */
+   int reorth;           /* 0 = one classical Gram-Schmidt pass (default), 1 = two passes     */
    int ml_levels;        /* multilevel: max levels (0 = automatic)                            */
    int ml_smooth;        /* multilevel: smoothing sweeps per level per half-cycle             */
    int reserved[7];

@@ -15,7 +15,7 @@
 // does NOT overwrite the tracer variable (the reference ignores SuperLU's info, :395-405);
 // -n is parsed as before but only sizes the rank count of the distributed flavour.
 // Extra knobs come from the environment so legacy invocations keep working:
-//   NKP_RTOL NKP_MAX_ITERS NKP_RESTART NKP_PRECOND(none|column|multilevel) NKP_KRYLOV(fgmres|bicgstab)
+//   NKP_RTOL NKP_MAX_ITERS NKP_RESTART NKP_PRECOND(none|column|multilevel) NKP_KRYLOV(fgmres|bicgstab) NKP_ML_SMOOTH
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -164,6 +164,7 @@ static void options_from_env (nkp_options *o)
    if ((e = getenv ("NKP_RTOL")) && !parse_to_double ((char *) e, &d)) o->rtol = d;
    if ((e = getenv ("NKP_MAX_ITERS")) && !parse_to_int ((char *) e, &i)) o->max_iters = i;
    if ((e = getenv ("NKP_RESTART")) && !parse_to_int ((char *) e, &i)) o->restart = i;
+   if ((e = getenv ("NKP_ML_SMOOTH")) && !parse_to_int ((char *) e, &i)) o->ml_smooth = i;
    if ((e = getenv ("NKP_PRECOND"))) {
       if (!strcmp (e, "none")) o->precond = NKP_PRECOND_NONE;
       else if (!strcmp (e, "column")) o->precond = NKP_PRECOND_COLUMN_JACOBI;

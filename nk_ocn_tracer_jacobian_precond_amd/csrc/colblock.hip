@@ -314,34 +314,34 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
       const double2 *src = reinterpret_cast<const double2 *> (fac_t + grp_base[g]);
       double2 *dst = reinterpret_cast<double2 *> (fl);
       const int cnt2 = ((2 * P + 1) * ml * gw) >> 1;
-      // batches of 8 loads in flight per lane before the first LDS store waits on them
-      for (int i0 = lane; i0 < cnt2; i0 += 8 * NKP_WAVE) {
-         double2 t[8];
+      // the right-hand side and a batch of 20 factor loads per lane are all in flight before the first LDS
+      // store waits on them (a group of 8 columns x 64 levels x 5 diagonals is exactly one batch)
+      double tr[8];
 #pragma unroll
-         for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < 8; u++) {
+         const int i = lane + u * NKP_WAVE;
+         tr[u] = (i < nrows) ? rhs[(int64_t) R0 + i] : 0.0;
+      }
+      for (int i0 = lane; i0 < cnt2; i0 += 20 * NKP_WAVE) {
+         double2 t[20];
+#pragma unroll
+         for (int u = 0; u < 20; u++) {
             const int i = i0 + u * NKP_WAVE;
             t[u] = (i < cnt2) ? src[i] : make_double2 (0.0, 0.0);
          }
 #pragma unroll
-         for (int u = 0; u < 8; u++) {
+         for (int u = 0; u < 20; u++) {
             const int i = i0 + u * NKP_WAVE;
             if (i < cnt2) dst[i] = t[u];
          }
       }
-   }
-   for (int i0 = lane; i0 < nrows; i0 += 8 * NKP_WAVE) {
-      double t[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-         const int i = i0 + u * NKP_WAVE;
-         t[u] = (i < nrows) ? rhs[(int64_t) R0 + i] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-         const int i = i0 + u * NKP_WAVE;
-         if (i < nrows) lds[LDS_PAD (i)] = t[u];
+         const int i = lane + u * NKP_WAVE;
+         if (i < nrows) lds[LDS_PAD (i)] = tr[u];
       }
    }
+   for (int i = lane + 8 * NKP_WAVE; i < nrows; i += NKP_WAVE) lds[LDS_PAD (i)] = rhs[(int64_t) R0 + i];
    __syncthreads ();
 
    if (lane < nb) {
@@ -357,26 +357,34 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
       // forward: y_k = ((r_k - l(k,k-P) y_{k-P}) ... - l(k,k-1) y_{k-1})   (far diagonal first, like the column sweep)
       // steps k >= len need no predicate: their factors are zero-padded, so they compute 0 - 0*x = 0;
       // the only branch left is wave-uniform (k < ml), which keeps the LDS reads hoistable
+      // ml is a multiple of 8 (layout builder), so the only branch is one wave-uniform test per 8 steps and
+      // the 8*P factor reads of a chunk are issued together, ahead of the dependent arithmetic
 #pragma unroll
-      for (int k = 0; k < MAXL; k++) {
-         if (k < ml) {
-            double y = v[k];
+      for (int k0 = 0; k0 < MAXL; k0 += 8) {
+         if (k0 < ml) {
 #pragma unroll
-            for (int q = P; q >= 1; q--)
-               if (k - q >= 0) y -= ft[(P - q) * dstride + k * gw] * v[k - q];
-            v[k] = y;
+            for (int k = k0; k < k0 + 8; k++) {
+               double y = v[k];
+#pragma unroll
+               for (int q = P; q >= 1; q--)
+                  if (k - q >= 0) y -= ft[(P - q) * dstride + k * gw] * v[k - q];
+               v[k] = y;
+            }
          }
       }
       // backward: x_k = (((y_k - u(k,k+P) x_{k+P}) ... - u(k,k+1) x_{k+1}) * (1/u_kk)
 #pragma unroll
-      for (int k = MAXL - 1; k >= 0; k--) {
-         if (k < ml) {
-            double x = v[k];
+      for (int k0 = MAXL - 8; k0 >= 0; k0 -= 8) {
+         if (k0 < ml) {
 #pragma unroll
-            for (int q = P; q >= 1; q--)
-               if (k + q < MAXL) x -= ft[(P + q) * dstride + k * gw] * v[k + q];
-            x *= ft[P * dstride + k * gw];
-            v[k] = x;
+            for (int k = k0 + 7; k >= k0; k--) {
+               double x = v[k];
+#pragma unroll
+               for (int q = P; q >= 1; q--)
+                  if (k + q < MAXL) x -= ft[(P + q) * dstride + k * gw] * v[k + q];
+               x *= ft[P * dstride + k * gw];
+               v[k] = x;
+            }
          }
       }
 #pragma unroll
@@ -427,7 +435,7 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    int gw = 8;
    if (const char *e = getenv ("NKP_COLGROUP")) gw = atoi (e);
    if (gw != 8 && gw != 16 && gw != 32 && gw != 64) gw = 8;
-   while (gw > 8 && (size_t) ((2 * B.P + 2) * B.max_len * gw) * sizeof (double) > 56 * 1024) gw >>= 1;
+   while (gw > 8 && (size_t) ((2 * B.P + 2) * ((B.max_len + 7) & ~7) * gw) * sizeof (double) > 56 * 1024) gw >>= 1;
    B.gw = gw;
    long long total = 0;
    int lds_need = 0, fac_need = 0;
@@ -438,6 +446,7 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
          const int cnt = std::min (gw, ranges[r + 1] - b);
          int m = 0;
          for (int c = b; c < b + cnt; c++) m = std::max (m, h_blk_start[c + 1] - h_blk_start[c]);
+         m = (m + 7) & ~7;                          // the apply kernel steps in chunks of 8 (zero-padded factors)
          const int rows = h_blk_start[b + cnt] - h_blk_start[b];
          lds_need = std::max (lds_need, LDS_PAD (rows) + 2);
          fac_need = std::max (fac_need, ndiag * m * gw);

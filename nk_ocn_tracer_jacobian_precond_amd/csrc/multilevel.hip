@@ -279,6 +279,20 @@ bool upload (T **dst, const T *src, size_t count, size_t *bytes)
    return true;
 }
 
+// same with `pad` zeroed extra elements (the SpMV reads matrix entries in aligned pairs)
+template <class T>
+bool upload_padded (T **dst, const T *src, size_t count, size_t pad, size_t *bytes)
+{
+   void *q = nullptr;
+   const size_t b = (count + pad) * sizeof (T);
+   if (hipMalloc (&q, b) != hipSuccess) return false;
+   if (hipMemset (q, 0, b) != hipSuccess) { (void) hipFree (q); return false; }
+   if (count && hipMemcpy (q, src, count * sizeof (T), hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree (q); return false; }
+   *dst = (T *) q;
+   *bytes += b;
+   return true;
+}
+
 }  // namespace
 
 // ================================================================ setup
@@ -454,8 +468,8 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       V.L.nnz = prow[nl];
       V.L.nrowblk = nrb0 + nrb1;
       bool ok = upload (&V.L.rowptr, prow.data (), (size_t) nl + 1, &H.device_bytes) &&
-                upload (&V.L.colind, pcol.data (), (size_t) prow[nl], &H.device_bytes) &&
-                upload (&V.L.val, pval.data (), (size_t) prow[nl], &H.device_bytes) &&
+                upload_padded (&V.L.colind, pcol.data (), (size_t) prow[nl], 2, &H.device_bytes) &&
+                upload_padded (&V.L.val, pval.data (), (size_t) prow[nl], 2, &H.device_bytes) &&
                 upload (&V.L.rowblk, rb.data (), rb.size (), &H.device_bytes) &&
                 upload (&V.x, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
                 upload (&V.b, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&

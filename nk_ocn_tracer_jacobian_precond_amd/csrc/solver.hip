@@ -56,16 +56,16 @@ extern "C" int nkp_default_options (nkp_options *opt)
    opt->struct_size = (int) sizeof (nkp_options);
    opt->precond = NKP_PRECOND_MULTILEVEL;
    opt->krylov = NKP_KRYLOV_FGMRES;
-   opt->restart = 100;
+   opt->restart = 200;
    opt->max_iters = 20000;
    opt->rtol = 1.0e-10;
    opt->atol = 0.0;
    opt->device = -1;
    opt->verbose = 0;
    opt->rank = 0;
-   opt->reorth = 1;
+   opt->reorth = 0;
    opt->ml_levels = 0;
-   opt->ml_smooth = 2;
+   opt->ml_smooth = 3;
    return NKP_OK;
 }
 
@@ -261,8 +261,8 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    s->A.n = n;
    s->A.nnz = M.nnz;
    TRY (dev_alloc (s, &s->A.rowptr, (size_t) n + 1));
-   TRY (dev_alloc (s, &s->A.colind, (size_t) M.nnz));
-   TRY (dev_alloc (s, &s->A.val, (size_t) M.nnz));
+   TRY (dev_alloc (s, &s->A.colind, (size_t) M.nnz + 2));      // +2: the SpMV reads entries in aligned pairs
+   TRY (dev_alloc (s, &s->A.val, (size_t) M.nnz + 2));
    TRYHIP (hipMemcpy (s->A.rowptr, M.rowptr, ((size_t) n + 1) * sizeof (int), hipMemcpyHostToDevice));
    if (M.nnz) {
       TRYHIP (hipMemcpy (s->A.colind, M.colind, (size_t) M.nnz * sizeof (int), hipMemcpyHostToDevice));

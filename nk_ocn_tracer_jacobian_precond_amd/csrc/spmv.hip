@@ -19,7 +19,7 @@
 #define SPMV_LDS_NNZ 2048
 #define SPMV_MAX_ROWS 256
 
-template <int MODE>   // 0: y = A x   1: y = b - A x   2: y = |A||x| + |b|
+template <int MODE, int VAR>   // MODE 0: y = A x   1: y = b - A x   2: y = |A||x| + |b| ; VAR: load flavour
 __global__ __launch_bounds__ (SPMV_THREADS)
 void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk, int per_xcd,
                              const int *__restrict__ rowptr, const int *__restrict__ colind,
@@ -60,11 +60,37 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       return;
    }
 
-   // phase 1: coalesced stream of (val, colind), gather x, stage products
+   // phase 1: coalesced stream of (val, colind), gather x through L2, products staged in LDS
+   if (VAR & 1) {
+      // 16-byte / 8-byte pairs: the block's entry range is widened to even boundaries, out-of-range halves masked
+      typedef double dbl2_t __attribute__ ((ext_vector_type (2)));
+      typedef int int2_t __attribute__ ((ext_vector_type (2)));
+      const int a0 = e0 & ~1;
+      const int npair = ((e1 + 1) >> 1) - (a0 >> 1);
+      const dbl2_t *val2 = reinterpret_cast<const dbl2_t *> (val + a0);
+      const int2_t *col2 = reinterpret_cast<const int2_t *> (colind + a0);
+#pragma unroll 4
+      for (int p = tid; p < npair; p += SPMV_THREADS) {
+         const dbl2_t v = (VAR & 2) ? __builtin_nontemporal_load (val2 + p) : val2[p];
+         const int2_t c = (VAR & 2) ? __builtin_nontemporal_load (col2 + p) : col2[p];
+         const int k = a0 + 2 * p - e0;                      // LDS slot of the pair's first entry (may be -1)
+         if (k >= 0) {
+            const double q = v.x * x[c.x];
+            prod[k] = (MODE == 2) ? fabs (q) : q;
+         }
+         if (k + 1 < cnt) {
+            const double q = v.y * x[c.y];
+            prod[k + 1] = (MODE == 2) ? fabs (q) : q;
+         }
+      }
+   } else {
 #pragma unroll 8
-   for (int k = tid; k < cnt; k += SPMV_THREADS) {
-      double p = val[e0 + k] * x[colind[e0 + k]];
-      prod[k] = (MODE == 2) ? fabs (p) : p;
+      for (int k = tid; k < cnt; k += SPMV_THREADS) {
+         const double v = (VAR & 2) ? __builtin_nontemporal_load (val + e0 + k) : val[e0 + k];
+         const int c = (VAR & 2) ? __builtin_nontemporal_load (colind + e0 + k) : colind[e0 + k];
+         const double q = v * x[c];
+         prod[k] = (MODE == 2) ? fabs (q) : q;
+      }
    }
    __syncthreads ();
 
@@ -100,13 +126,37 @@ void build_rowblocks_host (int64_t n, const int *rowptr, int **rowblk_out, int *
    *nrowblk_out = nb;
 }
 
+static int spmv_variant ()
+{
+   static int v = -1;
+   if (v < 0) {
+      const char *e = getenv ("NKP_SPMV_VARIANT");
+      v = e ? atoi (e) & 3 : 0;
+   }
+   return v;
+}
+
+template <int MODE>
+static void launch_range (const CsrDev &A, int rb0, int cnt, const double *x, double *y, const double *b, hipStream_t st)
+{
+   if (cnt <= 0) return;
+   const int per_xcd = (cnt + 7) / 8;
+#define SPMV_GO(VV) hipLaunchKernelGGL ((csr_spmv_stream_kernel<MODE, VV>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st, \
+                                         A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.val, x, y, b)
+   switch (spmv_variant ()) {
+   case 1: SPMV_GO (1); break;
+   case 2: SPMV_GO (2); break;
+   case 3: SPMV_GO (3); break;
+   default: SPMV_GO (0); break;
+   }
+#undef SPMV_GO
+}
+
 template <int MODE>
 static void launch_mode (const CsrDev &A, const double *x, double *y, const double *b, hipStream_t st)
 {
    if (A.n == 0) return;
-   const int per_xcd = (A.nrowblk + 7) / 8;
-   hipLaunchKernelGGL ((csr_spmv_stream_kernel<MODE>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st,
-                       A.rowblk, 0, A.nrowblk, per_xcd, A.rowptr, A.colind, A.val, x, y, b);
+   launch_range<MODE> (A, 0, A.nrowblk, x, y, b, st);
 }
 
 void launch_csr_spmv (const CsrDev &A, const double *x, double *y, const double *b, int mode, hipStream_t st)
@@ -122,9 +172,5 @@ void launch_csr_abs_spmv (const CsrDev &A, const double *x, const double *b, dou
 
 void launch_csr_residual_range (const CsrDev &A, int rb0, int rb1, const double *x, const double *b, double *y, hipStream_t st)
 {
-   const int cnt = rb1 - rb0;
-   if (cnt <= 0) return;
-   const int per_xcd = (cnt + 7) / 8;
-   hipLaunchKernelGGL ((csr_spmv_stream_kernel<1>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st,
-                       A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.val, x, y, b);
+   launch_range<1> (A, rb0, rb1 - rb0, x, y, b, st);
 }

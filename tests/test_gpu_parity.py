@@ -183,7 +183,7 @@ def test_solve_iteration_parity_with_cpu_port(golden_by_name):
     g = golden_by_name("penta_12x10x6")
     b = g.rhs("IAGE")
     xo, io = ora.fgmres(g.rowptr, g.colind, g.val, g.blk_start, b, restart=60, rtol=1e-10)
-    with solver.NkpSolver(g.rowptr, g.colind, g.val, g.blk_start, restart=60, rtol=1e-10, precond=solver.PRECOND_COLUMN_JACOBI) as s:
+    with solver.NkpSolver(g.rowptr, g.colind, g.val, g.blk_start, restart=60, rtol=1e-10, reorth=1, precond=solver.PRECOND_COLUMN_JACOBI) as s:
         x, info = s.solve(b)
     assert abs(info["iters"] - io["iters"]) <= 2
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-7

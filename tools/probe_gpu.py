@@ -15,16 +15,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--grid", default="100x116x60")
 ap.add_argument("--adv", default="upwind3")
 ap.add_argument("--hmix", default="isop")
-ap.add_argument("--restart", type=int, default=100)
+ap.add_argument("--restart", type=int, default=200)
 ap.add_argument("--max-iters", type=int, default=20000)
 ap.add_argument("--rtol", type=float, default=1e-10)
 ap.add_argument("--precond", type=int, default=1)
 ap.add_argument("--krylov", type=int, default=0)
-ap.add_argument("--reorth", type=int, default=1)
+ap.add_argument("--reorth", type=int, default=0)
 ap.add_argument("--solve", type=int, default=1)
 ap.add_argument("--verbose", type=int, default=0)
 ap.add_argument("--no-geo", type=int, default=0)
-ap.add_argument("--ml-smooth", type=int, default=2)
+ap.add_argument("--ml-smooth", type=int, default=3)
 ap.add_argument("--ml-levels", type=int, default=0)
 ap.add_argument("--min-cos", type=float, default=0.3)
 a = ap.parse_args()
