@@ -474,6 +474,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
                 upload (&V.x, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
                 upload (&V.b, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
                 upload (&V.r, (const double *) nullptr, (size_t) nl, &H.device_bytes);
+      if (ok) ok = attach_spmv_codes (V.L, prow.data (), pcol.data (), rb.data (), &H.device_bytes) == 0;
       if (!ok) ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l);
       if (l == 0 && !upload (&H.perm0, N.perm.data (), (size_t) nl, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
 
@@ -544,7 +545,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 void ml_free (MlHierarchy &H)
 {
    for (MlLevel &V : H.lev) {
-      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.rowblk, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.fac_t, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
+      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.fac_t, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
       for (void *p : ptrs)
          if (p) (void) hipFree (p);
    }

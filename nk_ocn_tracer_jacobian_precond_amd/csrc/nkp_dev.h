@@ -16,7 +16,20 @@ struct CsrDev {
    // LDS staging buffer (or a single long row)
    int *rowblk = nullptr;      // [nrowblk+1]
    int nrowblk = 0;
+   // optional 2-byte column codes (internal format; the int32 colind stays for the setup kernels and
+   // as the fallback): entry e of row block b holds (row - rowblk[b]) | id << 8 and its column is
+   // row + dict[dict_ptr[b] + id], the block's dictionary of distinct (column - row) offsets.
+   // dict_ptr[b+1] == dict_ptr[b] marks a block whose dictionary would exceed 256 entries (plain path).
+   unsigned short *codes = nullptr;   // [nnz]
+   int *dict = nullptr;
+   int *dict_ptr = nullptr;           // [nrowblk+1]
 };
+
+// host helper: build the codes for a CSR matrix and its row blocks; returns the fraction of entries coded
+double build_spmv_codes_host (int64_t n, const int *rowptr, const int *colind, const int *rowblk, int nrowblk,
+                              unsigned short **codes_out, int **dict_out, int *ndict_out, int **dict_ptr_out);
+// upload them into A (device); 0 = ok
+int attach_spmv_codes (CsrDev &A, const int *h_rowptr, const int *h_colind, const int *h_rowblk, size_t *device_bytes);
 
 // y = A x (mode 0) or y = b - A x (mode 1)
 void launch_csr_spmv (const CsrDev &A, const double *x, double *y, const double *b, int mode, hipStream_t st);

@@ -118,7 +118,7 @@ static int dev_alloc (nkp_solver *s, T **p, size_t count)
 static void solver_free (nkp_solver *s)
 {
    if (!s) return;
-   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.fac_t, s->V, s->Z, s->w, s->r,
+   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.fac_t, s->V, s->Z, s->w, s->r,
                     s->x, s->b, s->t1, s->t2, s->partial, s->dscal, s->dint };
    for (void *p : ptrs)
       if (p) (void) hipFree (p);
@@ -275,6 +275,7 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
       rc = dev_alloc (s, &s->A.rowblk, (size_t) nrb + 1);
       if (rc == NKP_OK && hipMemcpy (s->A.rowblk, rb, ((size_t) nrb + 1) * sizeof (int), hipMemcpyHostToDevice) != hipSuccess)
          rc = fail (NKP_EDEVICE, "copy of row blocks failed");
+      if (rc == NKP_OK && attach_spmv_codes (s->A, M.rowptr, M.colind, rb, &s->device_bytes)) rc = fail (NKP_ENOMEM, "column codes could not be uploaded");
       free (rb);
       if (rc != NKP_OK) { solver_free (s); return rc; }
    }

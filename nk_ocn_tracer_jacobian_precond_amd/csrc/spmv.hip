@@ -24,9 +24,11 @@ __global__ __launch_bounds__ (SPMV_THREADS)
 void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk, int per_xcd,
                              const int *__restrict__ rowptr, const int *__restrict__ colind,
                              const double *__restrict__ val, const double *__restrict__ x,
-                             double *__restrict__ y, const double *__restrict__ b)
+                             double *__restrict__ y, const double *__restrict__ b,
+                             const unsigned short *__restrict__ codes, const int *__restrict__ dict, const int *__restrict__ dict_ptr)
 {
    __shared__ double prod[SPMV_LDS_NNZ];
+   __shared__ int dict_s[256];
    __shared__ double wsum[SPMV_THREADS / NKP_WAVE];
 
    const int xcd = blockIdx.x & 7;
@@ -39,6 +41,9 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
    const int r0 = rowblk[lb], r1 = rowblk[lb + 1];
    const int e0 = rowptr[r0], e1 = rowptr[r1];
    const int cnt = e1 - e0;
+   // this lane's row bounds for phase 2, requested now so their latency hides under phase 1
+   int seg0 = 0, seg1 = 0;
+   if (r0 + tid < r1) { seg0 = rowptr[r0 + tid]; seg1 = rowptr[r0 + tid + 1]; }
 
    if (cnt > SPMV_LDS_NNZ) {
       // a single long row (the partitioner never packs several rows past the LDS budget)
@@ -60,8 +65,36 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       return;
    }
 
+   if (VAR == 8) {
+      // TIMING-ONLY: pure stream of the two arrays, no gather, no LDS, no row sums
+      double acc = 0.0;
+#pragma unroll 8
+      for (int k = tid; k < cnt; k += SPMV_THREADS) acc += val[e0 + k] * (double) colind[e0 + k];
+      if (acc == 123.456) y[r0] = acc;
+      return;
+   }
    // phase 1: coalesced stream of (val, colind), gather x through L2, products staged in LDS
-   if (VAR & 1) {
+   if (VAR == 4) {
+      // 2-byte column codes: 10 instead of 12 bytes per entry off HBM
+      const int d0 = dict_ptr[rb0 + lb], nd = dict_ptr[rb0 + lb + 1] - d0;
+      if (nd > 0) {
+         for (int i = tid; i < nd; i += SPMV_THREADS) dict_s[i] = dict[d0 + i];
+         __syncthreads ();
+#pragma unroll 8
+         for (int k = tid; k < cnt; k += SPMV_THREADS) {
+            const unsigned int code = codes[e0 + k];
+            const int c = r0 + (int) (code & 255u) + dict_s[code >> 8];
+            const double q = val[e0 + k] * x[c];
+            prod[k] = (MODE == 2) ? fabs (q) : q;
+         }
+      } else {
+#pragma unroll 8
+         for (int k = tid; k < cnt; k += SPMV_THREADS) {
+            const double q = val[e0 + k] * x[colind[e0 + k]];
+            prod[k] = (MODE == 2) ? fabs (q) : q;
+         }
+      }
+   } else if (VAR & 1) {
       // 16-byte / 8-byte pairs: the block's entry range is widened to even boundaries, out-of-range halves masked
       typedef double dbl2_t __attribute__ ((ext_vector_type (2)));
       typedef int int2_t __attribute__ ((ext_vector_type (2)));
@@ -83,6 +116,15 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
             prod[k + 1] = (MODE == 2) ? fabs (q) : q;
          }
       }
+   } else if (VAR >= 5) {
+      // TIMING-ONLY ablations (wrong results by design): 5 = no x gather, 6 = no row sums, 7 = no value stream
+#pragma unroll 8
+      for (int k = tid; k < cnt; k += SPMV_THREADS) {
+         const double v = (VAR == 7) ? 1.0 : val[e0 + k];
+         const int c = colind[e0 + k];
+         const double q = v * ((VAR == 5) ? (double) c : x[c]);
+         prod[k] = q;
+      }
    } else {
 #pragma unroll 8
       for (int k = tid; k < cnt; k += SPMV_THREADS) {
@@ -93,16 +135,150 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       }
    }
    __syncthreads ();
+   if (VAR == 6) {
+      if (tid == 0) y[r0] = prod[0] + prod[cnt - 1];
+      return;
+   }
 
    // phase 2: one lane per row sums its LDS segment (fixed order => deterministic)
    const int r = r0 + tid;
    if (r < r1) {
-      const int s0 = rowptr[r] - e0, s1 = rowptr[r + 1] - e0;
+      const int s0 = seg0 - e0, s1 = seg1 - e0;
       double acc = 0.0;
+#pragma unroll 4
       for (int k = s0; k < s1; k++) acc += prod[k];
       if (MODE == 1) acc = b[r] - acc;
       if (MODE == 2) acc += fabs (b[r]);
       y[r] = acc;
+   }
+}
+
+// ---------------------------------------------------------------- software-pipelined variant
+// Ablations on the 1 degree matrix (rocprof, this file's VAR 5-8): the bare (val, colind) stream runs at
+// 6.1 TB/s, but a workgroup that streams, THEN gathers x, THEN sums rows exposes three latencies in
+// series and the whole kernel lands at 4.2 TB/s.  Here a persistent workgroup walks a contiguous run of
+// row blocks and requests block i+1's stream (24 registers per lane) before it consumes block i's
+// gathers, so the stream latency hides under the gather + LDS + row-sum phases of the previous block.
+// Same products, same per-row summation order => bit-identical results.
+#define SPMV_SLOTS (SPMV_LDS_NNZ / SPMV_THREADS)
+
+template <int MODE>
+__global__ __launch_bounds__ (SPMV_THREADS)
+void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk,
+                           const int *__restrict__ rowptr, const int *__restrict__ colind,
+                           const double *__restrict__ val, const double *__restrict__ x,
+                           double *__restrict__ y, const double *__restrict__ b)
+{
+   __shared__ double prod[SPMV_LDS_NNZ];
+   __shared__ double wsum[SPMV_THREADS / NKP_WAVE];
+   const int tid = threadIdx.x;
+   const int *rowblk = rowblk_all + rb0;
+   // XCD-aware contiguous run of row blocks for this workgroup
+   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+   const int per_xcd = (nrowblk + 7) / 8;
+   const int xb0 = min (xcd * per_xcd, nrowblk), xb1 = min (xb0 + per_xcd, nrowblk);
+   const int chunk = (xb1 - xb0 + wg_per_xcd - 1) / wg_per_xcd;
+   int lb = xb0 + idx * chunk;
+   const int lb_end = min (lb + chunk, xb1);
+   if (lb >= lb_end) return;
+
+   int r0 = rowblk[lb], r1 = rowblk[lb + 1];
+   int e0 = rowptr[r0], e1 = rowptr[r1];
+   double v[SPMV_SLOTS];
+   int c[SPMV_SLOTS];
+   int seg0 = 0, seg1 = 0;
+#pragma unroll
+   for (int u = 0; u < SPMV_SLOTS; u++) {
+      const int e = e0 + tid + u * SPMV_THREADS;
+      const bool ok = e < e1 && e - e0 < SPMV_LDS_NNZ;
+      v[u] = ok ? val[e] : 0.0;
+      c[u] = ok ? colind[e] : 0;
+   }
+   if (r0 + tid < r1) { seg0 = rowptr[r0 + tid]; seg1 = rowptr[r0 + tid + 1]; }
+
+   for (;;) {
+      const int cnt = e1 - e0;
+      const bool have_next = lb + 1 < lb_end;
+      // descriptors of the next block (it starts where this one ends)
+      int nr1 = r1, ne1 = e1;
+      if (have_next) { nr1 = rowblk[lb + 2]; ne1 = rowptr[nr1]; }
+
+      if (cnt > SPMV_LDS_NNZ) {
+         // a single long row: strided accumulate + block reduction (tree order)
+         double acc = 0.0;
+         for (int e = e0 + tid; e < e1; e += SPMV_THREADS) {
+            const double p = val[e] * x[colind[e]];
+            acc += (MODE == 2) ? fabs (p) : p;
+         }
+         for (int off = NKP_WAVE / 2; off > 0; off >>= 1) acc += __shfl_down (acc, off);
+         if ((tid & (NKP_WAVE - 1)) == 0) wsum[tid / NKP_WAVE] = acc;
+         __syncthreads ();
+         if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < SPMV_THREADS / NKP_WAVE; w++) t += wsum[w];
+            if (MODE == 1) t = b[r0] - t;
+            if (MODE == 2) t += fabs (b[r0]);
+            y[r0] = t;
+         }
+         __syncthreads ();
+      } else {
+         // gathers of this block, then the NEXT block's stream requests, then consume the gathers
+         double xg[SPMV_SLOTS];
+#pragma unroll
+         for (int u = 0; u < SPMV_SLOTS; u++) xg[u] = (tid + u * SPMV_THREADS < cnt) ? x[c[u]] : 0.0;
+         double nv[SPMV_SLOTS];
+         int nc[SPMV_SLOTS];
+         int nseg0 = 0, nseg1 = 0;
+#pragma unroll
+         for (int u = 0; u < SPMV_SLOTS; u++) {
+            const int e = e1 + tid + u * SPMV_THREADS;
+            const bool ok = have_next && e < ne1 && e - e1 < SPMV_LDS_NNZ;
+            nv[u] = ok ? val[e] : 0.0;
+            nc[u] = ok ? colind[e] : 0;
+         }
+         if (have_next && r1 + tid < nr1) { nseg0 = rowptr[r1 + tid]; nseg1 = rowptr[r1 + tid + 1]; }
+#pragma unroll
+         for (int u = 0; u < SPMV_SLOTS; u++) {
+            const int k = tid + u * SPMV_THREADS;
+            if (k < cnt) {
+               const double q = v[u] * xg[u];
+               prod[k] = (MODE == 2) ? fabs (q) : q;
+            }
+         }
+         __syncthreads ();
+         const int r = r0 + tid;
+         if (r < r1) {
+            const int s0 = seg0 - e0, s1 = seg1 - e0;
+            double acc = 0.0;
+#pragma unroll 4
+            for (int k = s0; k < s1; k++) acc += prod[k];
+            if (MODE == 1) acc = b[r] - acc;
+            if (MODE == 2) acc += fabs (b[r]);
+            y[r] = acc;
+         }
+         __syncthreads ();
+#pragma unroll
+         for (int u = 0; u < SPMV_SLOTS; u++) { v[u] = nv[u]; c[u] = nc[u]; }
+         seg0 = nseg0;
+         seg1 = nseg1;
+         if (!have_next) break;
+         lb++;
+         r0 = r1; r1 = nr1; e0 = e1; e1 = ne1;
+         continue;
+      }
+      // after a long-row block the prefetched registers are stale: reload for the next block
+      if (!have_next) break;
+      lb++;
+      r0 = r1; r1 = nr1; e0 = e1; e1 = ne1;
+#pragma unroll
+      for (int u = 0; u < SPMV_SLOTS; u++) {
+         const int e = e0 + tid + u * SPMV_THREADS;
+         const bool ok = e < e1 && e - e0 < SPMV_LDS_NNZ;
+         v[u] = ok ? val[e] : 0.0;
+         c[u] = ok ? colind[e] : 0;
+      }
+      seg0 = seg1 = 0;
+      if (r0 + tid < r1) { seg0 = rowptr[r0 + tid]; seg1 = rowptr[r0 + tid + 1]; }
    }
 }
 
@@ -131,7 +307,18 @@ static int spmv_variant ()
    static int v = -1;
    if (v < 0) {
       const char *e = getenv ("NKP_SPMV_VARIANT");
-      v = e ? atoi (e) & 3 : 0;
+      v = e ? atoi (e) : 4;
+      if (v < 0 || v > 8) v = 4;
+   }
+   return v;
+}
+
+static int spmv_pipe_min ()
+{
+   static int v = -1;
+   if (v < 0) {
+      const char *e = getenv ("NKP_SPMV_PIPE_MIN");
+      v = e ? atoi (e) : 1024;
    }
    return v;
 }
@@ -141,12 +328,31 @@ static void launch_range (const CsrDev &A, int rb0, int cnt, const double *x, do
 {
    if (cnt <= 0) return;
    const int per_xcd = (cnt + 7) / 8;
+   if (spmv_variant () == 4 && cnt >= spmv_pipe_min ()) {
+      // runs of ~3 row blocks per workgroup: long enough to pipeline, short enough to balance the tail
+      // (same-process A/B at 1 degree: 6 per CU 199 us, 24 per CU 184 us, 48 per CU 177 us)
+      static int per_cu = -1;
+      if (per_cu < 0) { const char *e = getenv ("NKP_SPMV_WGS"); per_cu = (e && atoi (e) > 0) ? atoi (e) : 48; }
+      int wgs = cnt / 3;
+      if (wgs > 256 * per_cu) wgs = 256 * per_cu;
+      wgs &= ~7;
+      if (wgs < 8) wgs = 8;
+      hipLaunchKernelGGL ((csr_spmv_pipe_kernel<MODE>), dim3 (wgs), dim3 (SPMV_THREADS), 0, st, A.rowblk, rb0, cnt, A.rowptr, A.colind, A.val, x, y, b);
+      return;
+   }
 #define SPMV_GO(VV) hipLaunchKernelGGL ((csr_spmv_stream_kernel<MODE, VV>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st, \
-                                         A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.val, x, y, b)
-   switch (spmv_variant ()) {
+                                         A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.val, x, y, b, A.codes, A.dict, A.dict_ptr)
+   int var = spmv_variant ();
+   if (var == 4 && !A.codes) var = 0;
+   switch (var) {
    case 1: SPMV_GO (1); break;
    case 2: SPMV_GO (2); break;
    case 3: SPMV_GO (3); break;
+   case 4: SPMV_GO (4); break;
+   case 5: SPMV_GO (5); break;
+   case 6: SPMV_GO (6); break;
+   case 7: SPMV_GO (7); break;
+   case 8: SPMV_GO (8); break;
    default: SPMV_GO (0); break;
    }
 #undef SPMV_GO
@@ -173,4 +379,73 @@ void launch_csr_abs_spmv (const CsrDev &A, const double *x, const double *b, dou
 void launch_csr_residual_range (const CsrDev &A, int rb0, int rb1, const double *x, const double *b, double *y, hipStream_t st)
 {
    launch_range<1> (A, rb0, rb1 - rb0, x, y, b, st);
+}
+
+// ---------------------------------------------------------------- 2-byte column codes (host build)
+#include <algorithm>
+#include <vector>
+
+double build_spmv_codes_host (int64_t n, const int *rowptr, const int *colind, const int *rowblk, int nrowblk,
+                              unsigned short **codes_out, int **dict_out, int *ndict_out, int **dict_ptr_out)
+{
+   const int64_t nnz = rowptr[n];
+   unsigned short *codes = (unsigned short *) malloc ((size_t) (nnz + 2) * sizeof (unsigned short));
+   int *dict_ptr = (int *) malloc ((size_t) (nrowblk + 1) * sizeof (int));
+   std::vector<int> dict;
+   std::vector<int> deltas;
+   int64_t coded = 0;
+   dict_ptr[0] = 0;
+   for (int b = 0; b < nrowblk; b++) {
+      const int r0 = rowblk[b], r1 = rowblk[b + 1];
+      const int e0 = rowptr[r0], e1 = rowptr[r1];
+      bool ok = (r1 - r0) <= 256 && (e1 - e0) <= SPMV_LDS_NNZ;
+      if (ok) {
+         deltas.clear ();
+         for (int r = r0; r < r1; r++)
+            for (int e = rowptr[r]; e < rowptr[r + 1]; e++) deltas.push_back (colind[e] - r);
+         std::sort (deltas.begin (), deltas.end ());
+         deltas.erase (std::unique (deltas.begin (), deltas.end ()), deltas.end ());
+         ok = deltas.size () <= 256 && !deltas.empty ();
+      }
+      if (ok) {
+         for (int r = r0; r < r1; r++)
+            for (int e = rowptr[r]; e < rowptr[r + 1]; e++) {
+               const int id = (int) (std::lower_bound (deltas.begin (), deltas.end (), colind[e] - r) - deltas.begin ());
+               codes[e] = (unsigned short) ((r - r0) | (id << 8));
+            }
+         dict.insert (dict.end (), deltas.begin (), deltas.end ());
+         coded += e1 - e0;
+      } else
+         for (int e = e0; e < e1; e++) codes[e] = 0;
+      dict_ptr[b + 1] = (int) dict.size ();
+   }
+   int *d = (int *) malloc ((dict.size () + 1) * sizeof (int));
+   std::copy (dict.begin (), dict.end (), d);
+   *codes_out = codes;
+   *dict_out = d;
+   *ndict_out = (int) dict.size ();
+   *dict_ptr_out = dict_ptr;
+   return nnz ? (double) coded / (double) nnz : 1.0;
+}
+
+int attach_spmv_codes (CsrDev &A, const int *h_rowptr, const int *h_colind, const int *h_rowblk, size_t *device_bytes)
+{
+   // off by default: measured at 1 degree the 2-byte codes do not shorten the kernel (it is latency-, not
+   // byte-bound: removing the whole value stream did not either), and building them costs ~2.7 s of setup
+   const char *e = getenv ("NKP_SPMV_COMPRESS");
+   if (!e || atoi (e) == 0) return 0;
+   if (A.nnz == 0 || A.nrowblk == 0) return 0;
+   unsigned short *codes = nullptr;
+   int *dict = nullptr, *dict_ptr = nullptr, nd = 0;
+   build_spmv_codes_host (A.n, h_rowptr, h_colind, h_rowblk, A.nrowblk, &codes, &dict, &nd, &dict_ptr);
+   int rc = 0;
+   const size_t cb = (size_t) (A.nnz + 2) * sizeof (unsigned short), db = (size_t) (nd + 1) * sizeof (int), pb = (size_t) (A.nrowblk + 1) * sizeof (int);
+   if (hipMalloc ((void **) &A.codes, cb) != hipSuccess || hipMalloc ((void **) &A.dict, db) != hipSuccess || hipMalloc ((void **) &A.dict_ptr, pb) != hipSuccess) rc = 1;
+   if (!rc && (hipMemcpy (A.codes, codes, cb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy (A.dict, dict, db, hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy (A.dict_ptr, dict_ptr, pb, hipMemcpyHostToDevice) != hipSuccess)) rc = 1;
+   if (!rc) *device_bytes += cb + db + pb;
+   free (codes);
+   free (dict);
+   free (dict_ptr);
+   return rc;
 }

@@ -191,7 +191,7 @@ def test_solve_iteration_parity_with_cpu_port(golden_by_name):
 
 def test_unpreconditioned_and_zero_rhs(golden_by_name):
     g = golden_by_name("tri_12x10x6")
-    with solver.NkpSolver(g.rowptr, g.colind, g.val, None, precond=solver.PRECOND_NONE, restart=330, max_iters=3000, rtol=1e-10) as s:
+    with solver.NkpSolver(g.rowptr, g.colind, g.val, None, precond=solver.PRECOND_NONE, restart=330, max_iters=3000, rtol=1e-10, reorth=1) as s:
         x, info = s.solve(np.zeros(g.n))
         assert info["iters"] == 0 and not x.any()
         x, info = s.solve(g.rhs("IAGE"))
