@@ -197,8 +197,18 @@ def main():
     pre_ms = s.time_kernel(1, reps=50)
     it_ms = {f"j{j}": s.time_kernel(2, reps=10, arg=j) for j in (0, a.restart // 2, a.restart - 1)}
 
+    # HBM bytes per SpMV launch from the PMC counters: collected in separate rocprofv3 --pmc passes
+    # (FETCH_SIZE, WRITE_SIZE) and committed under profiles/; used only when it is this exact workload
+    traffic = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r1_spmv_pmc.json")))
+        if rec.get("n") == n_global and rec.get("nnz") == p.nnz and not distributed:
+            traffic = rec["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     if rank != 0:
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
         return
     iters = [i["iters"] for i in infos]
     out = {
@@ -224,8 +234,8 @@ def main():
                   "relres_checked_with_torch": relres_check, "setup_s": t_setup, "generate_s": t_gen,
                   "levels": s.get_int("levels"), "device_MB": s.get_int("device_bytes") / 1e6,
                   "precond_apply_ms": pre_ms, "krylov_iteration_ms": it_ms},
-        "roofline": {"kernel": "csr_spmv_stream_kernel<0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"kernel": "csr_spmv_pipe_kernel<0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms},
     }
     if not a.no_cpu_baseline:

@@ -263,3 +263,19 @@ def test_cli_running_out_of_names(tmp_path, golden_by_name):
     shutil.copy(g.tracer_path, dst)
     r = subprocess.run([os.path.join(BIN, "solve_ABglobal"), "-v", "OCMIP_BGC_PO4", g.matrix_path, dst], capture_output=True, text=True)
     assert r.returncode == 1 and "ran out of var names" in r.stderr
+
+
+def test_coupled_tracers_with_grid_positions():
+    """Two coupled tracers (tracer-major rows, reference src/matrix.c:778-784, 955-961): the multilevel setup
+    must aggregate columns per tracer only; solution checked against the oracle's direct solve."""
+    p = synth.generate(imt=16, jmt=12, km=6, adv="upwind3", hmix="isop", coupled_tracer_cnt=2, seed=9)
+    blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 2)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 2)
+    assert blk.size - 1 == ci.size == 2 * (p.col_start().size - 1)
+    b = np.random.default_rng(4).standard_normal(p.flat_len)
+    x_ref, berr = ora.direct_solve(p.rowptr, p.colind, p.nzval, b)
+    for kw in (dict(col_i=ci, col_j=cj), {}):
+        with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, coupled_tracer_cnt=2, rtol=1e-12, **kw) as s:
+            x, info = s.solve(b)
+        assert info["relres"] <= 1e-10
+        assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 1e-7
