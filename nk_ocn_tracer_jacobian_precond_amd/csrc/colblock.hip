@@ -300,15 +300,24 @@ __global__ __launch_bounds__ (NKP_WAVE)
 void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *__restrict__ grp_b0, const int *__restrict__ grp_nb,
                                   const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
                                   const double *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
-                                  int gw, int rhs_slots)
+                                  int gw, int rhs_slots, const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp)
 {
    extern __shared__ double lds[];            // [rhs_slots] staged right-hand side | [(2P+1)*ml*gw] the group's factors
    const int g = blockIdx.x + g_first;
    const int lane = threadIdx.x;
-   const int b0 = grp_b0[g], nb = grp_nb[g], ml = grp_maxlen[g];
-   const int R0 = blk_start[b0], R1 = blk_start[b0 + nb];
-   const int nrows = R1 - R0;
+   // every index this wave needs depends on g alone: one round trip, not a chain through blk_start
+   const int nb = grp_nb[g], ml = grp_maxlen[g];
+   const int R0 = grp_row0[g], nrows = grp_row0[ngrp + g];
+   int s_pre = 0, len_pre = 0;
+   if (lane < gw) { s_pre = col_slot[g * gw + lane]; len_pre = col_slot[(ngrp + g) * gw + lane]; }
    double *fl = lds + rhs_slots;
+   // the accumulate target is requested together with the right-hand side
+   double tz[8];
+#pragma unroll
+   for (int u = 0; u < 8; u++) {
+      const int i = lane + u * NKP_WAVE;
+      tz[u] = (accumulate && i < nrows) ? z[(int64_t) R0 + i] : 0.0;
+   }
    // bulk, fully coalesced staging: every load is independent, so the whole group is in flight at once
    {
       const double2 *src = reinterpret_cast<const double2 *> (fac_t + grp_base[g]);
@@ -345,8 +354,8 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
    __syncthreads ();
 
    if (lane < nb) {
-      const int s = blk_start[b0 + lane] - R0;
-      const int len = blk_start[b0 + lane + 1] - blk_start[b0 + lane];
+      const int s = s_pre;
+      const int len = len_pre;
       const double *ft = fl + lane;
       const int dstride = ml * gw;
       // the whole column lives in registers: no LDS write sits between two LDS reads, so the compiler
@@ -393,19 +402,12 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
    }
    __syncthreads ();
    if (accumulate) {
-      for (int i0 = lane; i0 < nrows; i0 += 8 * NKP_WAVE) {
-         double t[8];
 #pragma unroll
-         for (int u = 0; u < 8; u++) {
-            const int i = i0 + u * NKP_WAVE;
-            t[u] = (i < nrows) ? z[(int64_t) R0 + i] : 0.0;
-         }
-#pragma unroll
-         for (int u = 0; u < 8; u++) {
-            const int i = i0 + u * NKP_WAVE;
-            if (i < nrows) z[(int64_t) R0 + i] = t[u] + lds[LDS_PAD (i)];
-         }
+      for (int u = 0; u < 8; u++) {
+         const int i = lane + u * NKP_WAVE;
+         if (i < nrows) z[(int64_t) R0 + i] = tz[u] + lds[LDS_PAD (i)];
       }
+      for (int i = lane + 8 * NKP_WAVE; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] += lds[LDS_PAD (i)];
    } else
       for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
 }
@@ -429,7 +431,7 @@ static int up (T **dst, const std::vector<T> &src, size_t *bytes)
 int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const int *ranges, int nranges,
                                 int *grp_first, size_t *device_bytes, hipStream_t st)
 {
-   std::vector<int> b0, nb, ml;
+   std::vector<int> b0, nb, ml, row0, nrow, cslot, clen;
    std::vector<long long> base;
    // columns per wave: the group's factors + right-hand side must fit LDS several times per CU
    int gw = 8;
@@ -450,6 +452,12 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
          const int rows = h_blk_start[b + cnt] - h_blk_start[b];
          lds_need = std::max (lds_need, LDS_PAD (rows) + 2);
          fac_need = std::max (fac_need, ndiag * m * gw);
+         row0.push_back (h_blk_start[b]);
+         nrow.push_back (rows);
+         for (int c = 0; c < gw; c++) {
+            cslot.push_back (c < cnt ? h_blk_start[b + c] - h_blk_start[b] : 0);
+            clen.push_back (c < cnt ? h_blk_start[b + c + 1] - h_blk_start[b + c] : 0);
+         }
          b0.push_back (b);
          nb.push_back (cnt);
          ml.push_back (m);
@@ -467,6 +475,9 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    if ((rc = up (&B.grp_b0, b0, device_bytes)) || (rc = up (&B.grp_nb, nb, device_bytes)) || (rc = up (&B.grp_maxlen, ml, device_bytes)) ||
        (rc = up (&B.grp_base, base, device_bytes)))
       return rc;
+   row0.insert (row0.end (), nrow.begin (), nrow.end ());
+   cslot.insert (cslot.end (), clen.begin (), clen.end ());
+   if ((rc = up (&B.grp_row0, row0, device_bytes)) || (rc = up (&B.col_slot, cslot, device_bytes))) return rc;
    void *q = nullptr;
    hipError_t e = hipMalloc (&q, (size_t) (total ? total : 1) * sizeof (double));
    if (e != hipSuccess) return (int) e;
@@ -499,7 +510,7 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
       else LANES_LAUNCH2 (PP, 128);                                                                                        \
    } while (0)
 #define LANES_LAUNCH2(PP, ML) hipLaunchKernelGGL ((colblock_apply_lanes_kernel<PP, ML>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.blk_start, B.grp_b0, \
-                                              B.grp_nb, B.grp_maxlen, B.grp_base, g0, B.fac_t, r, z, accumulate, B.gw, B.rhs_slots)
+                                              B.grp_nb, B.grp_maxlen, B.grp_base, g0, B.fac_t, r, z, accumulate, B.gw, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp)
    if (B.P == 1) LANES_LAUNCH (1);
    else if (B.P == 2) LANES_LAUNCH (2);
    else LANES_LAUNCH (4);

@@ -22,6 +22,8 @@ struct MlHierarchy {
    int *perm0 = nullptr;        // level-0 row i holds original row perm0[i]
    double *coarse_inv = nullptr;   // dense inverse of the coarsest operator (row-major)
    int nu = 1;                  // Gauss-Seidel sweeps before and after the coarse correction
+   int nu_coarse = 1;           // ... on levels >= coarse_from
+   int coarse_from = 2;
    size_t device_bytes = 0;
 };
 

@@ -302,6 +302,9 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 {
 #define ML_FAIL(code, ...) do { snprintf (err, errlen, __VA_ARGS__); return (code); } while (0)
    H.nu = nu < 1 ? 1 : nu;
+   H.nu_coarse = H.nu;
+   if (const char *e = getenv ("NKP_ML_SMOOTH_COARSE")) { const int v = atoi (e); if (v >= 1) H.nu_coarse = v; }
+   if (const char *e = getenv ("NKP_ML_COARSE_FROM")) { const int v = atoi (e); if (v >= 1) H.coarse_from = v; }
    if (max_levels <= 0) max_levels = 12;
 
    // ---- natural-order data of every level (host)
@@ -545,7 +548,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 void ml_free (MlHierarchy &H)
 {
    for (MlLevel &V : H.lev) {
-      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.fac_t, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
+      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.grp_row0, V.B.col_slot, V.B.fac_t, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
       for (void *p : ptrs)
          if (p) (void) hipFree (p);
    }
@@ -578,14 +581,15 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
    launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.b, V.x, 0, st);
    launch_csr_residual_range (V.L, V.color_rb[1], V.color_rb[2], V.x, V.b, V.r, st);
    launch_colblock_apply_lanes (V.B, V.color_grp[1], V.color_grp[2], V.r, V.x, 1, st);
-   for (int s = 1; s < H.nu; s++) gs_sweep (V, false, st);
+   const int nu = (l >= H.coarse_from) ? H.nu_coarse : H.nu;
+   for (int s = 1; s < nu; s++) gs_sweep (V, false, st);
    // coarse-grid correction
    launch_csr_spmv (V.L, V.x, V.r, V.b, 1, st);
    MlLevel &C = H.lev[l + 1];
    launch_restrict_sum (V.rptr, V.ridx, V.r, C.b, V.nc, st);
    ml_cycle (H, l + 1, st);
    launch_prolong_add (V.cmap, C.x, V.x, V.n, st);
-   for (int s = 0; s < H.nu; s++) gs_sweep (V, true, st);
+   for (int s = 0; s < nu; s++) gs_sweep (V, true, st);
 }
 
 void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st)

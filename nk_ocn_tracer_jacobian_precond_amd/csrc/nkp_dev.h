@@ -59,6 +59,8 @@ struct ColBlocksDev {
    int *grp_nb = nullptr;      // [ngrp] blocks in the group (<= 64)
    int *grp_maxlen = nullptr;  // [ngrp] longest block of the group
    long long *grp_base = nullptr;   // [ngrp] offset into fac_t (doubles)
+   int *grp_row0 = nullptr;    // [ngrp] first row of the group, [ngrp..2ngrp) its row count (no dependent blk_start lookups)
+   int *col_slot = nullptr;    // [ngrp*gw] row offset of lane's column inside the group, [ngrp*gw..) its length
    double *fac_t = nullptr;
    int lds_doubles = 0;        // LDS staging need of the largest group (padded)
    int gw = 64;                // columns (lanes in use) per group

@@ -118,7 +118,7 @@ static int dev_alloc (nkp_solver *s, T **p, size_t count)
 static void solver_free (nkp_solver *s)
 {
    if (!s) return;
-   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.fac_t, s->V, s->Z, s->w, s->r,
+   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.grp_row0, s->B.col_slot, s->B.fac_t, s->V, s->Z, s->w, s->r,
                     s->x, s->b, s->t1, s->t2, s->partial, s->dscal, s->dint };
    for (void *p : ptrs)
       if (p) (void) hipFree (p);
