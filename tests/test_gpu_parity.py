@@ -279,3 +279,26 @@ def test_coupled_tracers_with_grid_positions():
             x, info = s.solve(b)
         assert info["relres"] <= 1e-10
         assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 1e-7
+
+
+def test_factor_only_call_and_edge_sizes(golden_by_name):
+    """nrhs = 0 is the reference's factor-only call (src/solve_ABglobal.c:350-353): legal, does nothing.
+    A water column longer than two wavefronts is refused with a clear message."""
+    import ctypes as C
+    g = golden_by_name("tri_12x10x6")
+    with solver.NkpSolver(g.rowptr, g.colind, g.val, g.blk_start) as s:
+        rc = s._lib.nkp_solve(s._h, None, 0, g.n, None, None, None)
+        assert rc == 0
+        b = g.rhs("IAGE")
+        two = np.stack([b, 2.0 * b])                       # nrhs = 2, column-major with ldb = n
+        berr = (C.c_double * 2)()
+        iters = (C.c_int * 2)()
+        relres = (C.c_double * 2)()
+        rc = s._lib.nkp_solve(s._h, two.ctypes.data_as(C.POINTER(C.c_double)), 2, g.n, berr, iters, relres)
+        assert rc == 0 and max(relres) <= 1e-10
+        assert np.linalg.norm(two[1] - 2.0 * two[0]) <= 1e-7 * np.linalg.norm(two[1])
+    n = 300
+    rp = np.arange(n + 1, dtype=np.int32)
+    with pytest.raises(solver.NkpError) as e:
+        solver.NkpSolver(rp, np.arange(n, dtype=np.int32), np.ones(n), np.array([0, n], np.int32))
+    assert e.value.code == -1 and "at most 128" in str(e.value)
