@@ -181,6 +181,14 @@ int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global,
                      const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt,
                      const nkp_comm_ops *comm);
 
+/* hipSetDevice for host programs that do not link HIP themselves (call before nkp_comm_rccl_init). */
+int nkp_set_device (int device);
+
+/* Collective: concatenate every rank's local slice (host, m_loc doubles) in rank order into
+ * x_global (host, n_global doubles, significant on rank 0 only) -- what put_B_dist does with
+ * MPI_Send/MPI_Recv tag 4 (src/solve_ABdist.c:377, 406). */
+int nkp_gather_root (nkp_solver *s, const double *x_loc, double *x_global);
+
 /* Host-only planning step of nkp_create_dist, exposed so the partition / halo logic can be tested
  * without a GPU: given this rank's rows and the row offsets of all ranks (starts[nranks+1]),
  * writes the remapped column indices (local rows -> [0, m_loc), halo -> m_loc + position in the

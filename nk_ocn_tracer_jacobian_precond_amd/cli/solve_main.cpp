@@ -189,8 +189,23 @@ int main (int argc, char *argv[])
    }
    if (parse_cmd_line (argc, argv))
       exit (EXIT_FAILURE);
-   if (iam != 0) {
-      // single-process build: extra ranks idle like ranks >= nprow*npcol do in the reference (:304)
+   int world = 1, local_rank = 0, use_comm = 0;
+   (void) local_rank;
+#ifdef NKP_DIST
+   // one process per GPU, launched with RANK / WORLD_SIZE / LOCAL_RANK in the environment (mpirun, torchrun,
+   // srun ... all set them or an equivalent); NKP_RCCL_ID_FILE names a file on a shared path through which
+   // rank 0 hands the RCCL unique id to the others (the reference uses MPI_COMM_WORLD, src/solve_ABdist.c:461)
+   {
+      const char *e;
+      int v;
+      if ((e = getenv ("WORLD_SIZE")) && !parse_to_int ((char *) e, &v) && v > 0) world = v;
+      local_rank = iam;
+      if ((e = getenv ("LOCAL_RANK")) && !parse_to_int ((char *) e, &v) && v >= 0) local_rank = v;
+   }
+#endif
+   use_comm = world > 1 || getenv ("NKP_FORCE_DIST") != NULL;       // the latter: exercise the RCCL path with one rank
+   if (iam != 0 && world == 1) {
+      // single-process run: extra ranks idle like ranks >= nprow*npcol do in the reference (:304)
       exit (EXIT_SUCCESS);
    }
    if (dbg_lvl) {
@@ -238,12 +253,75 @@ int main (int argc, char *argv[])
 
    // setup = the reference's factor-only call
    nkp_solver *solver = NULL;
+   int fst_row = 0, m_loc = flat_len;
    printf ("(%d) calling %s\n", iam, prog_solver);
    fflush (stdout);
 #ifdef NKP_DIST
-   // one rank owns every row: the reference's partition rule (src/solve_ABdist.c:141-144) with nprocs = 1
-   int info = nkp_create_dist (&solver, &opt, flat_len, 0, flat_len, nnz, rowptr, colind, nzval_row_wise, blk_start, nblk,
-                               coupled_tracer_cnt, NULL);
+   // the reference's partition rule (src/solve_ABdist.c:141-144), cuts snapped to water-column boundaries
+   int fst_blk = 0, nblk_loc = nblk;
+   nkp_comm_ops ops;
+   memset (&ops, 0, sizeof ops);
+   int info = 0;
+   if (use_comm) {
+      unsigned char id[128];
+      const char *idfile = getenv ("NKP_RCCL_ID_FILE");
+      if (idfile == NULL) {
+         fprintf (stderr, "(%d) WORLD_SIZE = %d needs NKP_RCCL_ID_FILE (a path every rank can read)\n", iam, world);
+         exit (EXIT_FAILURE);
+      }
+      opt.device = local_rank;
+      if (nkp_set_device (local_rank)) {
+         fprintf (stderr, "(%d) %s\n", iam, nkp_last_error ());
+         exit (EXIT_FAILURE);
+      }
+      if (iam == 0) {
+         char tmpname[4096];
+         snprintf (tmpname, sizeof tmpname, "%s.tmp", idfile);
+         FILE *f = NULL;
+         if (nkp_comm_unique_id (id) || (f = fopen (tmpname, "wb")) == NULL || fwrite (id, 1, sizeof id, f) != sizeof id || fclose (f) || rename (tmpname, idfile)) {
+            fprintf (stderr, "(%d) could not publish the RCCL unique id through %s\n", iam, idfile);
+            exit (EXIT_FAILURE);
+         }
+      } else {
+         int ok = 0;
+         for (int tries = 0; tries < 1200 && !ok; tries++) {       // up to two minutes
+            FILE *f = fopen (idfile, "rb");
+            if (f) {
+               ok = fread (id, 1, sizeof id, f) == sizeof id;
+               fclose (f);
+            }
+            if (!ok) usleep (100000);
+         }
+         if (!ok) {
+            fprintf (stderr, "(%d) timed out waiting for the RCCL unique id in %s\n", iam, idfile);
+            exit (EXIT_FAILURE);
+         }
+      }
+      if (nkp_comm_rccl_init (&ops, id, iam, world)) {
+         fprintf (stderr, "(%d) nkp_comm_rccl_init failed\n", iam);
+         exit (EXIT_FAILURE);
+      }
+      nkp_rowblock_partition_snapped (blk_start, nblk, world, iam, &fst_row, &m_loc, &fst_blk, &nblk_loc);
+   }
+   {
+      int_t *rowptr_loc = (int_t *) malloc ((size_t) (m_loc + 1) * sizeof (int_t));
+      int_t *blk_loc = (int_t *) malloc ((size_t) (nblk_loc + 1) * sizeof (int_t));
+      if (rowptr_loc == NULL || blk_loc == NULL) {
+         fprintf (stderr, "(%d) malloc failed in %s for the local row block\n", iam, argv[0]);
+         exit (EXIT_FAILURE);
+      }
+      const int_t e0 = rowptr[fst_row];
+      for (int r = 0; r <= m_loc; r++) rowptr_loc[r] = rowptr[fst_row + r] - e0;          // rebased (:170-175)
+      for (int b = 0; b <= nblk_loc; b++) blk_loc[b] = blk_start[fst_blk + b] - fst_row;
+      opt.col_i = col_i + fst_blk;
+      opt.col_j = col_j + fst_blk;
+      if (dbg_lvl > 1)
+         printf ("(%d) fst_row, flat_len_loc, nnz_loc = %d, %d, %d\n", iam, fst_row, m_loc, rowptr_loc[m_loc]);
+      info = nkp_create_dist (&solver, &opt, flat_len, fst_row, m_loc, rowptr_loc[m_loc], rowptr_loc, colind + e0, nzval_row_wise + e0,
+                              blk_loc, nblk_loc, coupled_tracer_cnt, use_comm ? &ops : NULL);
+      free (rowptr_loc);
+      free (blk_loc);
+   }
 #else
    int info = nkp_create (&solver, &opt, flat_len, nnz, rowptr, colind, nzval_row_wise, blk_start, nblk, coupled_tracer_cnt);
 #endif
@@ -288,7 +366,8 @@ int main (int argc, char *argv[])
       int iters = 0;
       printf ("(%d) calling nkp_solve\n", iam);
       fflush (stdout);
-      info = nkp_solve (solver, B, 1, flat_len, &berr, &iters, &relres);
+      // every rank flattened the whole B; it solves for its own slice (ldb = m_loc, src/solve_ABdist.c:571)
+      info = nkp_solve (solver, B + fst_row, 1, m_loc, &berr, &iters, &relres);
       if (dbg_lvl)
          printf ("(%d) nkp_solve info = %d, iterations = %d, relres = %.3e, berr = %.3e\n", iam, info, iters, relres, berr);
       if (info) {
@@ -296,13 +375,28 @@ int main (int argc, char *argv[])
                   vars_per_solve[0], inout_fname);
          exit (EXIT_FAILURE);
       }
-      if (put_B_global (vars_per_solve, B))
+      if (use_comm) {
+         // slices back to rank 0 (reference put_B_dist, src/solve_ABdist.c:377-406)
+         double *X = (iam == 0) ? (double *) malloc ((size_t) (flat_len ? flat_len : 1) * sizeof (double)) : NULL;
+         if (nkp_gather_root (solver, B + fst_row, X)) {
+            fprintf (stderr, "(%d) %s\n", iam, nkp_last_error ());
+            exit (EXIT_FAILURE);
+         }
+         if (iam == 0) {
+            memcpy (B, X, (size_t) flat_len * sizeof (double));
+            free (X);
+         }
+      }
+      if (iam == 0 && put_B_global (vars_per_solve, B))
          exit (EXIT_FAILURE);
       for (int t = 0; t < coupled_tracer_cnt; t++)
          free (vars_per_solve[t]);
    }
 
    nkp_destroy (solver);
+#ifdef NKP_DIST
+   if (use_comm) nkp_comm_rccl_free (&ops);
+#endif
    free_ind_maps ();
    free (vars_per_solve);
    free (vars);

@@ -857,3 +857,42 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
    *out = s;
    return NKP_OK;
 }
+
+extern "C" int nkp_set_device (int device)
+{
+   HIPCHK (hipSetDevice (device));
+   return NKP_OK;
+}
+
+extern "C" int nkp_gather_root (nkp_solver *s, const double *x_loc, double *x_global)
+{
+   if (!s || !x_loc) return fail (NKP_EINVAL, "nkp_gather_root: NULL argument");
+   HIPCHK (hipSetDevice (s->device));
+   if (!s->dist.on) {
+      if (!x_global) return fail (NKP_EINVAL, "nkp_gather_root: NULL argument");
+      memcpy (x_global, x_loc, (size_t) s->n * sizeof (double));
+      return NKP_OK;
+   }
+   const int P = s->dist.ops.nranks, rank = s->dist.ops.rank;
+   std::vector<int64_t> sizes (P + 1, 0);
+   if (s->dist.ops.allgather_i64_host (s->dist.ops.ctx, s->n, sizes.data ())) return fail (NKP_ECOMM, "nkp_gather_root: allgather failed");
+   std::vector<int> scnt (P, 0), rcnt (P, 0);
+   scnt[0] = (int) s->n;                                  // everything goes to rank 0
+   int64_t total = 0;
+   if (rank == 0)
+      for (int p = 0; p < P; p++) { rcnt[p] = (int) sizes[p]; total += sizes[p]; }
+   double *dsend = s->t1, *drecv = nullptr;
+   HIPCHK (hipMemcpyAsync (dsend, x_loc, (size_t) s->n * sizeof (double), hipMemcpyHostToDevice, s->stream));
+   if (rank == 0) {
+      if (!x_global) return fail (NKP_EINVAL, "nkp_gather_root: rank 0 needs x_global");
+      HIPCHK (hipMalloc ((void **) &drecv, (size_t) (total ? total : 1) * sizeof (double)));
+   }
+   const int crc = s->dist.ops.alltoallv (s->dist.ops.ctx, dsend, scnt.data (), drecv ? (void *) drecv : (void *) s->t2, rcnt.data (), (void *) s->stream);
+   if (!crc && rank == 0) {
+      hipError_t e = hipMemcpyAsync (x_global, drecv, (size_t) total * sizeof (double), hipMemcpyDeviceToHost, s->stream);
+      if (e != hipSuccess) { (void) hipFree (drecv); return fail (NKP_EDEVICE, "nkp_gather_root: copy back failed"); }
+   }
+   HIPCHK (hipStreamSynchronize (s->stream));
+   if (drecv) (void) hipFree (drecv);
+   return crc ? fail (NKP_ECOMM, "nkp_gather_root: exchange failed") : NKP_OK;
+}

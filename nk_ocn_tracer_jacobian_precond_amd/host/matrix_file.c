@@ -262,3 +262,27 @@ int nkp_column_coords (int nblk, int *col_i, int *col_j)
          }
    return b == nblk ? 0 : 1;
 }
+
+/* the reference's contiguous split (src/solve_ABdist.c:141-144) with every cut moved to the nearest
+ * water-column boundary, so that no column straddles two ranks; blk_start has nblk + 1 entries */
+void nkp_rowblock_partition_snapped (const int_t *blk_start, int nblk, int nprocs, int rank, int *fst_row, int *m_loc, int *fst_blk, int *nblk_loc)
+{
+   int n = blk_start[nblk];
+   int cut[2];
+   for (int w = 0; w < 2; w++) {
+      int r = rank + w;
+      if (r <= 0) { cut[w] = 0; continue; }
+      if (r >= nprocs) { cut[w] = nblk; continue; }
+      long target = (long) r * (n / nprocs);
+      int lo = 0, hi = nblk;                          /* first block boundary >= target */
+      while (lo < hi) { int mid = (lo + hi) / 2; if (blk_start[mid] < target) lo = mid + 1; else hi = mid; }
+      int b = lo;
+      if (b > 0 && target - blk_start[b - 1] <= blk_start[b] - target) b--;
+      cut[w] = b;
+   }
+   if (cut[1] < cut[0]) cut[1] = cut[0];
+   *fst_blk = cut[0];
+   *nblk_loc = cut[1] - cut[0];
+   *fst_row = blk_start[cut[0]];
+   *m_loc = blk_start[cut[1]] - blk_start[cut[0]];
+}

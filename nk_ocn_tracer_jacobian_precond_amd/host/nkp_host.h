@@ -107,6 +107,8 @@ int nkp_var_nelems (char *fname, char *varname, size_t *nelems);
 /* Contiguous row-block partition of the reference's distributed solver
  * (src/solve_ABdist.c:141-144): m_loc = n / nprocs, the last rank takes the remainder. */
 void nkp_rowblock_partition (int n, int nprocs, int rank, int *fst_row, int *m_loc);
+/* ... with every cut snapped to the nearest water-column boundary (what the GPU solver needs). */
+void nkp_rowblock_partition_snapped (const int_t *blk_start, int nblk, int nprocs, int rank, int *fst_row, int *m_loc, int *fst_blk, int *nblk_loc);
 
 #ifdef __cplusplus
 }

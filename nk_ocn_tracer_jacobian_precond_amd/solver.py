@@ -25,7 +25,8 @@ ABI_SYMBOLS = [
     "nkp_default_options", "nkp_device_count", "nkp_create", "nkp_solve", "nkp_solve_device",
     "nkp_spmv", "nkp_spmv_device", "nkp_precond_apply", "nkp_multi_dot", "nkp_time_kernel",
     "nkp_get_int", "nkp_set_stream", "nkp_destroy", "nkp_last_error", "nkp_comm_unique_id",
-    "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host",
+    "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host", "nkp_set_device",
+    "nkp_gather_root",
 ]
 
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
@@ -93,6 +94,8 @@ def load_library(path=None):
     lib.nkp_comm_rccl_free.restype = None
     lib.nkp_create_dist.argtypes = [C.POINTER(vp), C.POINTER(NkpOptions), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                     i32p, i32p, f64p, i32p, C.c_int64, C.c_int, C.POINTER(NkpCommOps)]
+    lib.nkp_set_device.argtypes = [C.c_int]
+    lib.nkp_gather_root.argtypes = [vp, f64p, f64p]
     lib.nkp_dist_plan_host.argtypes = [C.c_int64, C.c_int64, i32p, i32p, C.c_int, C.c_int, C.POINTER(C.c_int64), i32p, i32p,
                                        C.POINTER(C.c_int64), i32p]
     if path == HIP_LIB_PATH:
