@@ -281,25 +281,29 @@ void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const d
 __global__ __launch_bounds__ (NKP_WAVE)
 void colblock_transpose_kernel (const int *__restrict__ blk_start, const int *__restrict__ grp_b0, const int *__restrict__ grp_nb,
                                 const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int ndiag, int64_t n,
-                                const double *__restrict__ fac, double *__restrict__ fac_t, int gw)
+                                const double *__restrict__ fac, double *__restrict__ fac_t, int gw, float *__restrict__ fac_tf)
 {
    const int g = blockIdx.x;
    const int lane = threadIdx.x;
    const int b0 = grp_b0[g], nb = grp_nb[g], ml = grp_maxlen[g];
-   double *ft = fac_t + grp_base[g];
+   const long long base = grp_base[g];
    int r0 = 0, len = 0;
    if (lane < nb) { r0 = blk_start[b0 + lane]; len = blk_start[b0 + lane + 1] - r0; }
    if (lane >= gw) return;
    for (int d = 0; d < ndiag; d++)
       for (int k = 0; k < ml; k++)
-         ft[((int64_t) d * ml + k) * gw + lane] = (k < len) ? fac[(int64_t) d * n + r0 + k] : 0.0;
+      {
+         const double v = (k < len) ? fac[(int64_t) d * n + r0 + k] : 0.0;
+         if (fac_tf) fac_tf[base + ((int64_t) d * ml + k) * gw + lane] = (float) v;
+         else fac_t[base + ((int64_t) d * ml + k) * gw + lane] = v;
+      }
 }
 
-template <int P, int MAXL>
+template <int P, int MAXL, class FT>
 __global__ __launch_bounds__ (NKP_WAVE)
 void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *__restrict__ grp_b0, const int *__restrict__ grp_nb,
                                   const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
-                                  const double *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
+                                  const FT *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
                                   int gw, int rhs_slots, const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp)
 {
    extern __shared__ double lds[];            // [rhs_slots] staged right-hand side | [(2P+1)*ml*gw] the group's factors
@@ -310,7 +314,7 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
    const int R0 = grp_row0[g], nrows = grp_row0[ngrp + g];
    int s_pre = 0, len_pre = 0;
    if (lane < gw) { s_pre = col_slot[g * gw + lane]; len_pre = col_slot[(ngrp + g) * gw + lane]; }
-   double *fl = lds + rhs_slots;
+   FT *fl = reinterpret_cast<FT *> (lds + rhs_slots);
    // the accumulate target is requested together with the right-hand side
    double tz[8];
 #pragma unroll
@@ -320,9 +324,10 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
    }
    // bulk, fully coalesced staging: every load is independent, so the whole group is in flight at once
    {
+      // 16-byte units of the group's factor block (ml*gw is a multiple of 64, so this is exact for f32 too)
       const double2 *src = reinterpret_cast<const double2 *> (fac_t + grp_base[g]);
       double2 *dst = reinterpret_cast<double2 *> (fl);
-      const int cnt2 = ((2 * P + 1) * ml * gw) >> 1;
+      const int cnt2 = (int) (((size_t) (2 * P + 1) * ml * gw * sizeof (FT)) >> 4);
       // the right-hand side and a batch of 20 factor loads per lane are all in flight before the first LDS
       // store waits on them (a group of 8 columns x 64 levels x 5 diagonals is exactly one batch)
       double tr[8];
@@ -356,7 +361,7 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
    if (lane < nb) {
       const int s = s_pre;
       const int len = len_pre;
-      const double *ft = fl + lane;
+      const FT *ft = fl + lane;
       const int dstride = ml * gw;
       // the whole column lives in registers: no LDS write sits between two LDS reads, so the compiler
       // can keep the (read-only) factor reads in flight ahead of the dependent arithmetic
@@ -376,7 +381,7 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
                double y = v[k];
 #pragma unroll
                for (int q = P; q >= 1; q--)
-                  if (k - q >= 0) y -= ft[(P - q) * dstride + k * gw] * v[k - q];
+                  if (k - q >= 0) y -= (double) ft[(P - q) * dstride + k * gw] * v[k - q];
                v[k] = y;
             }
          }
@@ -390,8 +395,8 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
                double x = v[k];
 #pragma unroll
                for (int q = P; q >= 1; q--)
-                  if (k + q < MAXL) x -= ft[(P + q) * dstride + k * gw] * v[k + q];
-               x *= ft[P * dstride + k * gw];
+                  if (k + q < MAXL) x -= (double) ft[(P + q) * dstride + k * gw] * v[k + q];
+               x *= (double) ft[P * dstride + k * gw];
                v[k] = x;
             }
          }
@@ -429,7 +434,7 @@ static int up (T **dst, const std::vector<T> &src, size_t *bytes)
 }
 
 int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const int *ranges, int nranges,
-                                int *grp_first, size_t *device_bytes, hipStream_t st)
+                                int *grp_first, size_t *device_bytes, hipStream_t st, int f32)
 {
    std::vector<int> b0, nb, ml, row0, nrow, cslot, clen;
    std::vector<long long> base;
@@ -469,7 +474,7 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    B.ngrp = (int) b0.size ();
    lds_need = (lds_need + 1) & ~1;                 // keep the factor area 16-byte aligned
    B.rhs_slots = lds_need;
-   lds_need += fac_need;
+   lds_need += f32 ? (fac_need + 1) / 2 : fac_need;      // doubles
    B.lds_doubles = lds_need;
    int rc;
    if ((rc = up (&B.grp_b0, b0, device_bytes)) || (rc = up (&B.grp_nb, nb, device_bytes)) || (rc = up (&B.grp_maxlen, ml, device_bytes)) ||
@@ -479,23 +484,24 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    cslot.insert (cslot.end (), clen.begin (), clen.end ());
    if ((rc = up (&B.grp_row0, row0, device_bytes)) || (rc = up (&B.col_slot, cslot, device_bytes))) return rc;
    void *q = nullptr;
-   hipError_t e = hipMalloc (&q, (size_t) (total ? total : 1) * sizeof (double));
+   const size_t fsz = f32 ? sizeof (float) : sizeof (double);
+   hipError_t e = hipMalloc (&q, (size_t) (total ? total : 1) * fsz);
    if (e != hipSuccess) return (int) e;
-   B.fac_t = (double *) q;
-   *device_bytes += (size_t) total * sizeof (double);
+   if (f32) B.fac_tf = (float *) q;
+   else B.fac_t = (double *) q;
+   *device_bytes += (size_t) total * fsz;
    if (B.ngrp)
       hipLaunchKernelGGL (colblock_transpose_kernel, dim3 (B.ngrp), dim3 (NKP_WAVE), 0, st, B.blk_start, B.grp_b0, B.grp_nb, B.grp_maxlen,
-                          B.grp_base, ndiag, B.n, B.fac, B.fac_t, gw);
+                          B.grp_base, ndiag, B.n, B.fac, B.fac_t, gw, B.fac_tf);
    // dynamic LDS above the default limit needs an explicit opt-in
    const int lds_bytes = lds_need * (int) sizeof (double);
    if (lds_bytes > 160 * 1024) return (int) hipErrorInvalidValue;
    if (lds_bytes > 48 * 1024) {
-      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<1, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+#define LDS_OPT_IN(PP, ML)                                                                                                              \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<PP, ML, double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<PP, ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
+      LDS_OPT_IN (1, 64); LDS_OPT_IN (2, 64); LDS_OPT_IN (4, 64); LDS_OPT_IN (1, 128); LDS_OPT_IN (2, 128); LDS_OPT_IN (4, 128);
+#undef LDS_OPT_IN
    }
    return (int) hipStreamSynchronize (st);
 }
@@ -509,8 +515,13 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
       if (B.max_len <= 64) LANES_LAUNCH2 (PP, 64);                                                                         \
       else LANES_LAUNCH2 (PP, 128);                                                                                        \
    } while (0)
-#define LANES_LAUNCH2(PP, ML) hipLaunchKernelGGL ((colblock_apply_lanes_kernel<PP, ML>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.blk_start, B.grp_b0, \
-                                              B.grp_nb, B.grp_maxlen, B.grp_base, g0, B.fac_t, r, z, accumulate, B.gw, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp)
+#define LANES_LAUNCH2(PP, ML)                                                                                                                                   \
+   do {                                                                                                                                                        \
+      if (B.fac_tf) hipLaunchKernelGGL ((colblock_apply_lanes_kernel<PP, ML, float>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.blk_start, B.grp_b0, B.grp_nb, \
+                                        B.grp_maxlen, B.grp_base, g0, B.fac_tf, r, z, accumulate, B.gw, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp);             \
+      else hipLaunchKernelGGL ((colblock_apply_lanes_kernel<PP, ML, double>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.blk_start, B.grp_b0, B.grp_nb,          \
+                               B.grp_maxlen, B.grp_base, g0, B.fac_t, r, z, accumulate, B.gw, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp);                       \
+   } while (0)
    if (B.P == 1) LANES_LAUNCH (1);
    else if (B.P == 2) LANES_LAUNCH (2);
    else LANES_LAUNCH (4);

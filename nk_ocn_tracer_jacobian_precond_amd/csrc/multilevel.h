@@ -24,6 +24,7 @@ struct MlHierarchy {
    int nu = 1;                  // Gauss-Seidel sweeps before and after the coarse correction
    int nu_coarse = 1;           // ... on levels >= coarse_from
    int coarse_from = 2;
+   int f32 = 1;                 // store level operators / factors in f32 (arithmetic stays f64)
    size_t device_bytes = 0;
 };
 

@@ -302,6 +302,8 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 {
 #define ML_FAIL(code, ...) do { snprintf (err, errlen, __VA_ARGS__); return (code); } while (0)
    H.nu = nu < 1 ? 1 : nu;
+   H.f32 = 1;                                     // level operators and factors stored in f32, arithmetic in f64
+   if (const char *e = getenv ("NKP_ML_F32")) H.f32 = atoi (e) != 0;
    H.nu_coarse = H.nu;
    if (const char *e = getenv ("NKP_ML_SMOOTH_COARSE")) { const int v = atoi (e); if (v >= 1) H.nu_coarse = v; }
    if (const char *e = getenv ("NKP_ML_COARSE_FROM")) { const int v = atoi (e); if (v >= 1) H.coarse_from = v; }
@@ -478,6 +480,10 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
                 upload (&V.b, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
                 upload (&V.r, (const double *) nullptr, (size_t) nl, &H.device_bytes);
       if (ok) ok = attach_spmv_codes (V.L, prow.data (), pcol.data (), rb.data (), &H.device_bytes) == 0;
+      if (ok && H.f32 && l < nlev - 1) {
+         std::vector<float> vf (pval.begin (), pval.begin () + prow[nl]);
+         ok = upload_padded (&V.L.valf, vf.data (), vf.size (), 2, &H.device_bytes);
+      }
       if (!ok) ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l);
       if (l == 0 && !upload (&H.perm0, N.perm.data (), (size_t) nl, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
 
@@ -508,7 +514,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          V.B.dropped = st2[1];
          {
             const int ranges[3] = { 0, N.ncol0, ncol };
-            const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st);
+            const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st, H.f32);
             if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
          }
          // transfer operators in permuted orders
@@ -548,7 +554,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 void ml_free (MlHierarchy &H)
 {
    for (MlLevel &V : H.lev) {
-      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.grp_row0, V.B.col_slot, V.B.fac_t, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
+      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.valf, V.B.fac_tf, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.grp_row0, V.B.col_slot, V.B.fac_t, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
       for (void *p : ptrs)
          if (p) (void) hipFree (p);
    }

@@ -12,6 +12,7 @@ struct CsrDev {
    int *rowptr = nullptr;      // [n+1]
    int *colind = nullptr;      // [nnz]
    double *val = nullptr;      // [nnz]
+   float *valf = nullptr;      // [nnz] optional f32 copy of val (preconditioner operators: f32 storage, f64 arithmetic)
    // CSR-stream row blocks: block b owns rows [rowblk[b], rowblk[b+1]) whose entries fit the
    // LDS staging buffer (or a single long row)
    int *rowblk = nullptr;      // [nrowblk+1]
@@ -62,6 +63,7 @@ struct ColBlocksDev {
    int *grp_row0 = nullptr;    // [ngrp] first row of the group, [ngrp..2ngrp) its row count (no dependent blk_start lookups)
    int *col_slot = nullptr;    // [ngrp*gw] row offset of lane's column inside the group, [ngrp*gw..) its length
    double *fac_t = nullptr;
+   float *fac_tf = nullptr;    // same layout in f32 (preconditioner: f32 storage, f64 arithmetic)
    int lds_doubles = 0;        // LDS staging need of the largest group (padded)
    int gw = 64;                // columns (lanes in use) per group
    int rhs_slots = 0;          // LDS doubles reserved for the staged right-hand side
@@ -71,7 +73,7 @@ struct ColBlocksDev {
 // range boundary (Gauss-Seidel colours).  grp_first[r] = first group of range r (nranges+1 out).
 // Returns 0 or a HIP error code cast to int.
 int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const int *ranges, int nranges,
-                                int *grp_first, size_t *device_bytes, hipStream_t st);
+                                int *grp_first, size_t *device_bytes, hipStream_t st, int f32 = 0);
 // groups [g0, g1): z (+)= M^-1 r, one water column per LANE, rhs staged through LDS
 void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const double *r, double *z, int accumulate, hipStream_t st);
 

@@ -19,11 +19,11 @@
 #define SPMV_LDS_NNZ 2048
 #define SPMV_MAX_ROWS 256
 
-template <int MODE, int VAR>   // MODE 0: y = A x   1: y = b - A x   2: y = |A||x| + |b| ; VAR: load flavour
+template <int MODE, int VAR, class VT>   // MODE 0: y = A x   1: y = b - A x   2: y = |A||x| + |b| ; VAR: load flavour ; VT: stored value type
 __global__ __launch_bounds__ (SPMV_THREADS)
 void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk, int per_xcd,
                              const int *__restrict__ rowptr, const int *__restrict__ colind,
-                             const double *__restrict__ val, const double *__restrict__ x,
+                             const VT *__restrict__ val, const double *__restrict__ x,
                              double *__restrict__ y, const double *__restrict__ b,
                              const unsigned short *__restrict__ codes, const int *__restrict__ dict, const int *__restrict__ dict_ptr)
 {
@@ -49,7 +49,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       // a single long row (the partitioner never packs several rows past the LDS budget)
       double acc = 0.0;
       for (int e = e0 + tid; e < e1; e += SPMV_THREADS) {
-         double p = val[e] * x[colind[e]];
+         double p = (double) val[e] * x[colind[e]];
          acc += (MODE == 2) ? fabs (p) : p;
       }
       for (int off = NKP_WAVE / 2; off > 0; off >>= 1) acc += __shfl_down (acc, off);
@@ -69,7 +69,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       // TIMING-ONLY: pure stream of the two arrays, no gather, no LDS, no row sums
       double acc = 0.0;
 #pragma unroll 8
-      for (int k = tid; k < cnt; k += SPMV_THREADS) acc += val[e0 + k] * (double) colind[e0 + k];
+      for (int k = tid; k < cnt; k += SPMV_THREADS) acc += (double) val[e0 + k] * (double) colind[e0 + k];
       if (acc == 123.456) y[r0] = acc;
       return;
    }
@@ -84,13 +84,13 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
          for (int k = tid; k < cnt; k += SPMV_THREADS) {
             const unsigned int code = codes[e0 + k];
             const int c = r0 + (int) (code & 255u) + dict_s[code >> 8];
-            const double q = val[e0 + k] * x[c];
+            const double q = (double) val[e0 + k] * x[c];
             prod[k] = (MODE == 2) ? fabs (q) : q;
          }
       } else {
 #pragma unroll 8
          for (int k = tid; k < cnt; k += SPMV_THREADS) {
-            const double q = val[e0 + k] * x[colind[e0 + k]];
+            const double q = (double) val[e0 + k] * x[colind[e0 + k]];
             prod[k] = (MODE == 2) ? fabs (q) : q;
          }
       }
@@ -100,7 +100,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       typedef int int2_t __attribute__ ((ext_vector_type (2)));
       const int a0 = e0 & ~1;
       const int npair = ((e1 + 1) >> 1) - (a0 >> 1);
-      const dbl2_t *val2 = reinterpret_cast<const dbl2_t *> (val + a0);
+      const dbl2_t *val2 = reinterpret_cast<const dbl2_t *> (reinterpret_cast<const double *> (val) + a0);
       const int2_t *col2 = reinterpret_cast<const int2_t *> (colind + a0);
 #pragma unroll 4
       for (int p = tid; p < npair; p += SPMV_THREADS) {
@@ -120,7 +120,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       // TIMING-ONLY ablations (wrong results by design): 5 = no x gather, 6 = no row sums, 7 = no value stream
 #pragma unroll 8
       for (int k = tid; k < cnt; k += SPMV_THREADS) {
-         const double v = (VAR == 7) ? 1.0 : val[e0 + k];
+         const double v = (VAR == 7) ? 1.0 : (double) val[e0 + k];
          const int c = colind[e0 + k];
          const double q = v * ((VAR == 5) ? (double) c : x[c]);
          prod[k] = q;
@@ -128,7 +128,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
    } else {
 #pragma unroll 8
       for (int k = tid; k < cnt; k += SPMV_THREADS) {
-         const double v = (VAR & 2) ? __builtin_nontemporal_load (val + e0 + k) : val[e0 + k];
+         const double v = (double) ((VAR & 2) ? __builtin_nontemporal_load (val + e0 + k) : val[e0 + k]);
          const int c = (VAR & 2) ? __builtin_nontemporal_load (colind + e0 + k) : colind[e0 + k];
          const double q = v * x[c];
          prod[k] = (MODE == 2) ? fabs (q) : q;
@@ -162,11 +162,11 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
 // Same products, same per-row summation order => bit-identical results.
 #define SPMV_SLOTS (SPMV_LDS_NNZ / SPMV_THREADS)
 
-template <int MODE>
+template <int MODE, class VT>
 __global__ __launch_bounds__ (SPMV_THREADS)
 void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk,
                            const int *__restrict__ rowptr, const int *__restrict__ colind,
-                           const double *__restrict__ val, const double *__restrict__ x,
+                           const VT *__restrict__ val, const double *__restrict__ x,
                            double *__restrict__ y, const double *__restrict__ b)
 {
    __shared__ double prod[SPMV_LDS_NNZ];
@@ -184,14 +184,14 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
 
    int r0 = rowblk[lb], r1 = rowblk[lb + 1];
    int e0 = rowptr[r0], e1 = rowptr[r1];
-   double v[SPMV_SLOTS];
+   VT v[SPMV_SLOTS];
    int c[SPMV_SLOTS];
    int seg0 = 0, seg1 = 0;
 #pragma unroll
    for (int u = 0; u < SPMV_SLOTS; u++) {
       const int e = e0 + tid + u * SPMV_THREADS;
       const bool ok = e < e1 && e - e0 < SPMV_LDS_NNZ;
-      v[u] = ok ? val[e] : 0.0;
+      v[u] = ok ? val[e] : (VT) 0;
       c[u] = ok ? colind[e] : 0;
    }
    if (r0 + tid < r1) { seg0 = rowptr[r0 + tid]; seg1 = rowptr[r0 + tid + 1]; }
@@ -207,7 +207,7 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
          // a single long row: strided accumulate + block reduction (tree order)
          double acc = 0.0;
          for (int e = e0 + tid; e < e1; e += SPMV_THREADS) {
-            const double p = val[e] * x[colind[e]];
+            const double p = (double) val[e] * x[colind[e]];
             acc += (MODE == 2) ? fabs (p) : p;
          }
          for (int off = NKP_WAVE / 2; off > 0; off >>= 1) acc += __shfl_down (acc, off);
@@ -226,14 +226,14 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
          double xg[SPMV_SLOTS];
 #pragma unroll
          for (int u = 0; u < SPMV_SLOTS; u++) xg[u] = (tid + u * SPMV_THREADS < cnt) ? x[c[u]] : 0.0;
-         double nv[SPMV_SLOTS];
+         VT nv[SPMV_SLOTS];
          int nc[SPMV_SLOTS];
          int nseg0 = 0, nseg1 = 0;
 #pragma unroll
          for (int u = 0; u < SPMV_SLOTS; u++) {
             const int e = e1 + tid + u * SPMV_THREADS;
             const bool ok = have_next && e < ne1 && e - e1 < SPMV_LDS_NNZ;
-            nv[u] = ok ? val[e] : 0.0;
+            nv[u] = ok ? val[e] : (VT) 0;
             nc[u] = ok ? colind[e] : 0;
          }
          if (have_next && r1 + tid < nr1) { nseg0 = rowptr[r1 + tid]; nseg1 = rowptr[r1 + tid + 1]; }
@@ -241,7 +241,7 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
          for (int u = 0; u < SPMV_SLOTS; u++) {
             const int k = tid + u * SPMV_THREADS;
             if (k < cnt) {
-               const double q = v[u] * xg[u];
+               const double q = (double) v[u] * xg[u];
                prod[k] = (MODE == 2) ? fabs (q) : q;
             }
          }
@@ -274,7 +274,7 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
       for (int u = 0; u < SPMV_SLOTS; u++) {
          const int e = e0 + tid + u * SPMV_THREADS;
          const bool ok = e < e1 && e - e0 < SPMV_LDS_NNZ;
-         v[u] = ok ? val[e] : 0.0;
+         v[u] = ok ? val[e] : (VT) 0;
          c[u] = ok ? colind[e] : 0;
       }
       seg0 = seg1 = 0;
@@ -337,10 +337,16 @@ static void launch_range (const CsrDev &A, int rb0, int cnt, const double *x, do
       if (wgs > 256 * per_cu) wgs = 256 * per_cu;
       wgs &= ~7;
       if (wgs < 8) wgs = 8;
-      hipLaunchKernelGGL ((csr_spmv_pipe_kernel<MODE>), dim3 (wgs), dim3 (SPMV_THREADS), 0, st, A.rowblk, rb0, cnt, A.rowptr, A.colind, A.val, x, y, b);
+      if (A.valf) hipLaunchKernelGGL ((csr_spmv_pipe_kernel<MODE, float>), dim3 (wgs), dim3 (SPMV_THREADS), 0, st, A.rowblk, rb0, cnt, A.rowptr, A.colind, A.valf, x, y, b);
+      else hipLaunchKernelGGL ((csr_spmv_pipe_kernel<MODE, double>), dim3 (wgs), dim3 (SPMV_THREADS), 0, st, A.rowblk, rb0, cnt, A.rowptr, A.colind, A.val, x, y, b);
       return;
    }
-#define SPMV_GO(VV) hipLaunchKernelGGL ((csr_spmv_stream_kernel<MODE, VV>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st, \
+   if (A.valf) {
+      hipLaunchKernelGGL ((csr_spmv_stream_kernel<MODE, 0, float>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st,
+                          A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.valf, x, y, b, A.codes, A.dict, A.dict_ptr);
+      return;
+   }
+#define SPMV_GO(VV) hipLaunchKernelGGL ((csr_spmv_stream_kernel<MODE, VV, double>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st, \
                                          A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.val, x, y, b, A.codes, A.dict, A.dict_ptr)
    int var = spmv_variant ();
    if (var == 4 && !A.codes) var = 0;
