@@ -44,15 +44,16 @@ static inline int red_grid (int64_t n)
 
 // ---------------------------------------------------------------- multi-dot
 // grid (nblk, nchunk).  partial[(chunk*nblk + blk)*(CHUNK+1) + c]; slot CHUNK of chunk 0 = w.w
+template <class VT, class VT2>
 __global__ __launch_bounds__ (B1_THREADS)
-void multi_dot_kernel (const double *__restrict__ V, int64_t ld, int k, const double *__restrict__ w,
+void multi_dot_kernel (const VT *__restrict__ V, int64_t ld, int k, const double *__restrict__ w,
                        int64_t n, double *__restrict__ partial)
 {
    __shared__ double sh[B1_THREADS / NKP_WAVE];
    const int chunk = blockIdx.y;
    const int j0 = chunk * NKP_DOT_CHUNK;
    const int kc = (k - j0) < NKP_DOT_CHUNK ? (k - j0) : NKP_DOT_CHUNK;
-   const double *Vc = V + (int64_t) j0 * ld;
+   const VT *Vc = V + (int64_t) j0 * ld;
    double acc[NKP_DOT_CHUNK];
 #pragma unroll
    for (int c = 0; c < NKP_DOT_CHUNK; c++) acc[c] = 0.0;
@@ -65,15 +66,15 @@ void multi_dot_kernel (const double *__restrict__ V, int64_t ld, int k, const do
 #pragma unroll
          for (int c = 0; c < NKP_DOT_CHUNK; c++)
             if (c < kc) {
-               const double2 v2 = *reinterpret_cast<const double2 *> (Vc + (int64_t) c * ld + i);
-               acc[c] += v2.x * w2.x + v2.y * w2.y;
+               const VT2 v2 = *reinterpret_cast<const VT2 *> (Vc + (int64_t) c * ld + i);
+               acc[c] += (double) v2.x * w2.x + (double) v2.y * w2.y;
             }
       } else {
          const double w1 = w[i];
          accw += w1 * w1;
 #pragma unroll
          for (int c = 0; c < NKP_DOT_CHUNK; c++)
-            if (c < kc) acc[c] += Vc[(int64_t) c * ld + i] * w1;
+            if (c < kc) acc[c] += (double) Vc[(int64_t) c * ld + i] * w1;
       }
    }
    double *out = partial + ((int64_t) chunk * gridDim.x + blockIdx.x) * (NKP_DOT_CHUNK + 1);
@@ -100,18 +101,20 @@ void multi_dot_finish_kernel (const double *__restrict__ partial, int nblk, int 
    if (threadIdx.x == 0) out[j] = s;
 }
 
-void launch_multi_dot (const double *V, int64_t ld, int k, const double *w, int64_t n, double *partial, double *out, hipStream_t st)
+void launch_multi_dot (const void *V, int v_f32, int64_t ld, int k, const double *w, int64_t n, double *partial, double *out, hipStream_t st)
 {
    const int g = red_grid (n);
    const int nchunk = k > 0 ? (k + NKP_DOT_CHUNK - 1) / NKP_DOT_CHUNK : 1;
-   hipLaunchKernelGGL (multi_dot_kernel, dim3 (g, nchunk), dim3 (B1_THREADS), 0, st, V, ld, k, w, n, partial);
+   if (v_f32) hipLaunchKernelGGL ((multi_dot_kernel<float, float2>), dim3 (g, nchunk), dim3 (B1_THREADS), 0, st, (const float *) V, ld, k, w, n, partial);
+   else hipLaunchKernelGGL ((multi_dot_kernel<double, double2>), dim3 (g, nchunk), dim3 (B1_THREADS), 0, st, (const double *) V, ld, k, w, n, partial);
    hipLaunchKernelGGL (multi_dot_finish_kernel, dim3 (k + 1), dim3 (NKP_WAVE), 0, st, partial, g, k, out);
 }
 
 // ---------------------------------------------------------------- w -= V h, with ||w||^2
 #define B1_MAX_K NKP_MAX_K
+template <class VT, class VT2>
 __global__ __launch_bounds__ (B1_THREADS)
-void update_w_kernel (const double *__restrict__ V, int64_t ld, int k, const double *__restrict__ h,
+void update_w_kernel (const VT *__restrict__ V, int64_t ld, int k, const double *__restrict__ h,
                       double *__restrict__ w, int64_t n, double *__restrict__ partial, double sign)
 {
    __shared__ double hs[B1_MAX_K];
@@ -125,17 +128,17 @@ void update_w_kernel (const double *__restrict__ V, int64_t ld, int k, const dou
          double2 a = *reinterpret_cast<const double2 *> (w + i);
          int j = 0;
          for (; j + 4 <= k; j += 4) {
-            const double2 v0 = *reinterpret_cast<const double2 *> (V + (int64_t) (j + 0) * ld + i);
-            const double2 v1 = *reinterpret_cast<const double2 *> (V + (int64_t) (j + 1) * ld + i);
-            const double2 v2 = *reinterpret_cast<const double2 *> (V + (int64_t) (j + 2) * ld + i);
-            const double2 v3 = *reinterpret_cast<const double2 *> (V + (int64_t) (j + 3) * ld + i);
+            const VT2 v0 = *reinterpret_cast<const VT2 *> (V + (int64_t) (j + 0) * ld + i);
+            const VT2 v1 = *reinterpret_cast<const VT2 *> (V + (int64_t) (j + 1) * ld + i);
+            const VT2 v2 = *reinterpret_cast<const VT2 *> (V + (int64_t) (j + 2) * ld + i);
+            const VT2 v3 = *reinterpret_cast<const VT2 *> (V + (int64_t) (j + 3) * ld + i);
             a.x += hs[j] * v0.x; a.y += hs[j] * v0.y;
             a.x += hs[j + 1] * v1.x; a.y += hs[j + 1] * v1.y;
             a.x += hs[j + 2] * v2.x; a.y += hs[j + 2] * v2.y;
             a.x += hs[j + 3] * v3.x; a.y += hs[j + 3] * v3.y;
          }
          for (; j < k; j++) {
-            const double2 v0 = *reinterpret_cast<const double2 *> (V + (int64_t) j * ld + i);
+            const VT2 v0 = *reinterpret_cast<const VT2 *> (V + (int64_t) j * ld + i);
             a.x += hs[j] * v0.x; a.y += hs[j] * v0.y;
          }
          *reinterpret_cast<double2 *> (w + i) = a;
@@ -162,22 +165,24 @@ void sum_partials_kernel (const double *__restrict__ partial, int nblk, double *
    if (threadIdx.x == 0) out[0] = s;
 }
 
-void launch_update_w (const double *V, int64_t ld, int k, const double *h, double *w, int64_t n, double *partial, double *out_nrm2, hipStream_t st)
+void launch_update_w (const void *V, int v_f32, int64_t ld, int k, const double *h, double *w, int64_t n, double *partial, double *out_nrm2, hipStream_t st)
 {
    const int g = red_grid (n);
-   hipLaunchKernelGGL (update_w_kernel, dim3 (g), dim3 (B1_THREADS), 0, st, V, ld, k, h, w, n, partial, -1.0);
+   if (v_f32) hipLaunchKernelGGL ((update_w_kernel<float, float2>), dim3 (g), dim3 (B1_THREADS), 0, st, (const float *) V, ld, k, h, w, n, partial, -1.0);
+   else hipLaunchKernelGGL ((update_w_kernel<double, double2>), dim3 (g), dim3 (B1_THREADS), 0, st, (const double *) V, ld, k, h, w, n, partial, -1.0);
    hipLaunchKernelGGL (sum_partials_kernel, dim3 (1), dim3 (NKP_WAVE), 0, st, partial, g, out_nrm2);
 }
 
 void launch_axpy_multi (const double *Z, int64_t ld, int k, const double *c, double *x, int64_t n, hipStream_t st)
 {
    const int g = red_grid (n);
-   hipLaunchKernelGGL (update_w_kernel, dim3 (g), dim3 (B1_THREADS), 0, st, Z, ld, k, c, x, n, (double *) nullptr, 1.0);
+   hipLaunchKernelGGL ((update_w_kernel<double, double2>), dim3 (g), dim3 (B1_THREADS), 0, st, Z, ld, k, c, x, n, (double *) nullptr, 1.0);
 }
 
 // ---------------------------------------------------------------- simple streams
+// y = alpha x ; optionally also yf = (float) (alpha x)  (f32 copy of a Krylov basis vector)
 __global__ __launch_bounds__ (B1_THREADS)
-void scale_to_kernel (const double *__restrict__ x, const double *__restrict__ alpha, double *__restrict__ y, int64_t n)
+void scale_to_kernel (const double *__restrict__ x, const double *__restrict__ alpha, double *__restrict__ y, float *__restrict__ yf, int64_t n)
 {
    const double a = alpha[0];
    const int64_t stride = (int64_t) gridDim.x * B1_THREADS * 2;
@@ -186,14 +191,17 @@ void scale_to_kernel (const double *__restrict__ x, const double *__restrict__ a
          double2 v = *reinterpret_cast<const double2 *> (x + i);
          v.x *= a; v.y *= a;
          *reinterpret_cast<double2 *> (y + i) = v;
-      } else
+         if (yf) *reinterpret_cast<float2 *> (yf + i) = make_float2 ((float) v.x, (float) v.y);
+      } else {
          y[i] = a * x[i];
+         if (yf) yf[i] = (float) (a * x[i]);
+      }
    }
 }
 
-void launch_scale_to (const double *x, const double *alpha_dev, double *y, int64_t n, hipStream_t st)
+void launch_scale_to (const double *x, const double *alpha_dev, double *y, float *yf, int64_t n, hipStream_t st)
 {
-   hipLaunchKernelGGL (scale_to_kernel, dim3 (red_grid (n)), dim3 (B1_THREADS), 0, st, x, alpha_dev, y, n);
+   hipLaunchKernelGGL (scale_to_kernel, dim3 (red_grid (n)), dim3 (B1_THREADS), 0, st, x, alpha_dev, y, yf, n);
 }
 
 __global__ __launch_bounds__ (B1_THREADS)

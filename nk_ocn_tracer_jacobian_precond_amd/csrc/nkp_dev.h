@@ -92,11 +92,11 @@ void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const d
 
 // partial[(chunk*NKP_RED_BLOCKS + blk)*8 + c] ; then finish sums over blk in fixed order
 // out[j] = sum_i V[j*ld+i] * w[i]  j<k ;  out[k] = sum_i w[i]^2
-void launch_multi_dot (const double *V, int64_t ld, int k, const double *w, int64_t n, double *partial, double *out, hipStream_t st);
+void launch_multi_dot (const void *V, int v_f32, int64_t ld, int k, const double *w, int64_t n, double *partial, double *out, hipStream_t st);
 // w -= sum_j h[j] V_j (j<k);  out_nrm2[0] = ||w_new||^2 (via partial, deterministic)
-void launch_update_w (const double *V, int64_t ld, int k, const double *h, double *w, int64_t n, double *partial, double *out_nrm2, hipStream_t st);
+void launch_update_w (const void *V, int v_f32, int64_t ld, int k, const double *h, double *w, int64_t n, double *partial, double *out_nrm2, hipStream_t st);
 // y = alpha[0] * x   (alpha on device)
-void launch_scale_to (const double *x, const double *alpha_dev, double *y, int64_t n, hipStream_t st);
+void launch_scale_to (const double *x, const double *alpha_dev, double *y, float *yf, int64_t n, hipStream_t st);
 // x += sum_j c[j] Z_j (j<k)   (c on device)
 void launch_axpy_multi (const double *Z, int64_t ld, int k, const double *c, double *x, int64_t n, hipStream_t st);
 // out[0] = sum x_i*y_i

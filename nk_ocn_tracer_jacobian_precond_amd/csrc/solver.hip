@@ -66,6 +66,7 @@ extern "C" int nkp_default_options (nkp_options *opt)
    opt->reorth = 0;
    opt->ml_levels = 0;
    opt->ml_smooth = 3;
+   opt->basis_f32 = 1;
    return NKP_OK;
 }
 
@@ -91,6 +92,8 @@ struct nkp_solver {
    int64_t n = 0, ld = 0;
    int m = 0;
    // work vectors
+   bool vf32 = false;              // Krylov basis stored as float (stride ld floats inside the V allocation)
+   double *vcur = nullptr;         // f64 copy of the newest basis vector (input of the next preconditioner call)
    double *V = nullptr, *Z = nullptr, *w = nullptr, *r = nullptr, *x = nullptr, *b = nullptr, *t1 = nullptr, *t2 = nullptr;
    double *partial = nullptr;       // reduction scratch
    double *dscal = nullptr;         // device scalars: h[m+2] | h2[m+2] | misc[16] | ycoef[m+1]
@@ -118,7 +121,7 @@ static int dev_alloc (nkp_solver *s, T **p, size_t count)
 static void solver_free (nkp_solver *s)
 {
    if (!s) return;
-   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.grp_row0, s->B.col_slot, s->B.fac_t, s->V, s->Z, s->w, s->r,
+   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.grp_row0, s->B.col_slot, s->B.fac_t, s->V, s->vcur, s->Z, s->w, s->r,
                     s->x, s->b, s->t1, s->t2, s->partial, s->dscal, s->dint };
    for (void *p : ptrs)
       if (p) (void) hipFree (p);
@@ -283,6 +286,8 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    // work space
    const int m = s->m;
    TRY (dev_alloc (s, &s->V, (size_t) s->ld * (size_t) (m + 1)));
+   TRY (dev_alloc (s, &s->vcur, (size_t) s->ld));
+   s->vf32 = opt.basis_f32 != 0;
    TRY (dev_alloc (s, &s->Z, (size_t) s->ld * (size_t) m));
    TRY (dev_alloc (s, &s->w, (size_t) s->ld));
    TRY (dev_alloc (s, &s->r, (size_t) s->ld));
@@ -411,23 +416,25 @@ static int dot_host (nkp_solver *s, const double *x, const double *y, double *ou
 static void arnoldi_step_device (nkp_solver *s, int j)
 {
    const int64_t ld = s->ld;
-   double *vj = s->V + (int64_t) j * ld, *zj = s->Z + (int64_t) j * ld;
+   double *zj = s->Z + (int64_t) j * ld;
+   const double *vj = s->vf32 ? s->vcur : s->V + (int64_t) j * ld;
    apply_precond (s, vj, zj);
    spmv_op (s, zj, s->w, nullptr, 0);
-   launch_multi_dot (s->V, ld, j + 1, s->w, s->n, s->partial, s->h_dev (), s->stream);
+   launch_multi_dot (s->V, s->vf32, ld, j + 1, s->w, s->n, s->partial, s->h_dev (), s->stream);
    allreduce_dev (s, s->h_dev (), j + 2, 0);                 // one allreduce per Gram-Schmidt pass
-   launch_update_w (s->V, ld, j + 1, s->h_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
+   launch_update_w (s->V, s->vf32, ld, j + 1, s->h_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
    if (s->opt.reorth) {
-      launch_multi_dot (s->V, ld, j + 1, s->w, s->n, s->partial, s->h2_dev (), s->stream);
+      launch_multi_dot (s->V, s->vf32, ld, j + 1, s->w, s->n, s->partial, s->h2_dev (), s->stream);
       allreduce_dev (s, s->h2_dev (), j + 2, 0);
-      launch_update_w (s->V, ld, j + 1, s->h2_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
+      launch_update_w (s->V, s->vf32, ld, j + 1, s->h2_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
       allreduce_dev (s, s->misc_dev (), 1, 0);
       launch_finish_column (s->h_dev (), s->h2_dev (), j + 1, s->misc_dev (), s->misc_dev () + 1, s->stream);
    } else {
       allreduce_dev (s, s->misc_dev (), 1, 0);
       launch_finish_column (s->h_dev (), nullptr, j + 1, s->misc_dev (), s->misc_dev () + 1, s->stream);
    }
-   launch_scale_to (s->w, s->misc_dev () + 1, s->V + (int64_t) (j + 1) * ld, s->n, s->stream);
+   if (s->vf32) launch_scale_to (s->w, s->misc_dev () + 1, s->vcur, (float *) s->V + (int64_t) (j + 1) * ld, s->n, s->stream);
+   else launch_scale_to (s->w, s->misc_dev () + 1, s->V + (int64_t) (j + 1) * ld, nullptr, s->n, s->stream);
 }
 
 static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
@@ -464,7 +471,8 @@ static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
       // v0 = r / beta
       s->hpin[0] = 1.0 / beta;
       HIPCHK (hipMemcpyAsync (s->misc_dev () + 1, s->hpin, sizeof (double), hipMemcpyHostToDevice, st));
-      launch_scale_to (s->r, s->misc_dev () + 1, s->V, n, st);
+      if (s->vf32) launch_scale_to (s->r, s->misc_dev () + 1, s->vcur, (float *) s->V, n, st);
+      else launch_scale_to (s->r, s->misc_dev () + 1, s->V, nullptr, n, st);
       HIPCHK (hipStreamSynchronize (st));      // hpin is reused below
       g[0] = beta;
       int j = 0;
@@ -695,10 +703,17 @@ extern "C" int nkp_multi_dot (nkp_solver *s, const double *V, int64_t ld, int k,
 {
    if (!s || !V || !w || !out || k < 0 || k > s->m + 1 || ld < s->n) return fail (NKP_EINVAL, "nkp_multi_dot: bad argument (k must be <= restart+1)");
    HIPCHK (hipSetDevice (s->device));
-   for (int j = 0; j < k; j++)
-      HIPCHK (hipMemcpyAsync (s->V + (int64_t) j * s->ld, V + (int64_t) j * ld, (size_t) s->n * sizeof (double), hipMemcpyHostToDevice, s->stream));
+   std::vector<float> vf;
+   for (int j = 0; j < k; j++) {
+      if (s->vf32) {
+         vf.assign (V + (int64_t) j * ld, V + (int64_t) j * ld + s->n);
+         HIPCHK (hipMemcpyAsync ((float *) s->V + (int64_t) j * s->ld, vf.data (), (size_t) s->n * sizeof (float), hipMemcpyHostToDevice, s->stream));
+         HIPCHK (hipStreamSynchronize (s->stream));        // vf is reused
+      } else
+         HIPCHK (hipMemcpyAsync (s->V + (int64_t) j * s->ld, V + (int64_t) j * ld, (size_t) s->n * sizeof (double), hipMemcpyHostToDevice, s->stream));
+   }
    HIPCHK (hipMemcpyAsync (s->w, w, (size_t) s->n * sizeof (double), hipMemcpyHostToDevice, s->stream));
-   launch_multi_dot (s->V, s->ld, k, s->w, s->n, s->partial, s->h_dev (), s->stream);
+   launch_multi_dot (s->V, s->vf32, s->ld, k, s->w, s->n, s->partial, s->h_dev (), s->stream);
    allreduce_dev (s, s->h_dev (), k + 1, 0);
    HIPCHK (hipMemcpyAsync (out, s->h_dev (), (size_t) (k + 1) * sizeof (double), hipMemcpyDeviceToHost, s->stream));
    HIPCHK (hipStreamSynchronize (s->stream));
@@ -717,7 +732,15 @@ extern "C" int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, dou
    launch_fill (s->t1, 1.0, s->n, s->stream);
    if (which == 2) {
       if (arg < 0 || arg >= s->m) return fail (NKP_EINVAL, "nkp_time_kernel: restart position out of range");
-      for (int j = 0; j <= arg + 1; j++) launch_fill (s->V + (int64_t) j * s->ld, 1.0 / (1.0 + j), s->n, s->stream);
+      // finite operands in whichever basis precision is active (f32 vectors are filled through their f64 twin)
+      for (int j = 0; j <= arg + 1; j++) {
+         launch_fill (s->t2, 1.0 / (1.0 + j), s->n, s->stream);
+         s->hpin[0] = 1.0;
+         HIPCHK (hipMemcpyAsync (s->misc_dev () + 1, s->hpin, sizeof (double), hipMemcpyHostToDevice, s->stream));
+         if (s->vf32) launch_scale_to (s->t2, s->misc_dev () + 1, s->vcur, (float *) s->V + (int64_t) j * s->ld, s->n, s->stream);
+         else launch_scale_to (s->t2, s->misc_dev () + 1, s->V + (int64_t) j * s->ld, nullptr, s->n, s->stream);
+         HIPCHK (hipStreamSynchronize (s->stream));
+      }
    }
    for (int pass = 0; pass < 2; pass++) {      // pass 0 = warm-up
       const int cnt = pass == 0 ? (reps < 3 ? reps : 3) : reps;

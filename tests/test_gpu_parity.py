@@ -147,14 +147,17 @@ def test_multi_dot_tolerance(medium):
     n = p.flat_len
     V = rng.standard_normal((19, n))
     w = rng.standard_normal(n)
-    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, restart=24, precond=solver.PRECOND_COLUMN_JACOBI) as s:
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, restart=24, precond=solver.PRECOND_COLUMN_JACOBI, basis_f32=0) as s:
         out = s.multi_dot(V, w)
         again = s.multi_dot(V, w)
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, restart=24, precond=solver.PRECOND_COLUMN_JACOBI, basis_f32=1) as s:
+        out32 = s.multi_dot(V, w)                                      # basis stored in f32: f32-level agreement
     assert np.array_equal(out, again)                                  # fixed-order reduction: reproducible
     ref = ora.multi_dot(V, w)
     scale = np.sqrt((V * V).sum(1) * (w @ w))
     assert np.all(np.abs(out[:19] - ref[:19]) <= 1e-13 * scale)        # f64, differs in summation order only
     assert abs(out[19] - ref[19]) <= 1e-13 * ref[19]
+    assert np.all(np.abs(out32[:19] - ref[:19]) <= 2e-7 * scale) and abs(out32[19] - ref[19]) <= 1e-13 * ref[19]
 
 
 @pytest.mark.parametrize("precond", [solver.PRECOND_COLUMN_JACOBI, solver.PRECOND_MULTILEVEL])
@@ -183,7 +186,7 @@ def test_solve_iteration_parity_with_cpu_port(golden_by_name):
     g = golden_by_name("penta_12x10x6")
     b = g.rhs("IAGE")
     xo, io = ora.fgmres(g.rowptr, g.colind, g.val, g.blk_start, b, restart=60, rtol=1e-10)
-    with solver.NkpSolver(g.rowptr, g.colind, g.val, g.blk_start, restart=60, rtol=1e-10, reorth=1, precond=solver.PRECOND_COLUMN_JACOBI) as s:
+    with solver.NkpSolver(g.rowptr, g.colind, g.val, g.blk_start, restart=60, rtol=1e-10, reorth=1, basis_f32=0, precond=solver.PRECOND_COLUMN_JACOBI) as s:
         x, info = s.solve(b)
     assert abs(info["iters"] - io["iters"]) <= 2
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) <= 1e-7
