@@ -367,7 +367,13 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       if (geo) {
          // 2 x 2 blocks of columns in (i, j), never across tracers; ids in order of first member
          std::vector<std::pair<std::array<int, 3>, int>> keys (ncol);
-         for (int c = 0; c < ncol; c++) keys[c] = { { N.gt[c], N.gj[c] >> 1, N.gi[c] >> 1 }, c };
+         // 2 x 2 on the big levels, 4 x 4 from level 3 down: every kernel of a small level runs at its latency
+         // floor, so fewer small levels pay (1 degree: 8 -> 6 levels, +5 % iterations, -14 % cycle time);
+         // NKP_ML_BIG_FROM=l moves the switch, -1 disables it (from level 2 it costs +68 % iterations)
+         static int big_from = -2;
+         if (big_from == -2) { const char *e = getenv ("NKP_ML_BIG_FROM"); big_from = e ? atoi (e) : 3; }
+         const int sh = (big_from >= 0 && l >= big_from) ? 2 : 1;
+         for (int c = 0; c < ncol; c++) keys[c] = { { N.gt[c], N.gj[c] >> sh, N.gi[c] >> sh }, c };
          std::vector<std::pair<std::array<int, 3>, int>> sorted (keys);
          std::sort (sorted.begin (), sorted.end ());
          std::vector<int> gid_sorted (ncol), first_member;
@@ -386,7 +392,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          for (int c = 0; c < ncol; c++) {
             const int a = newid[gid_sorted[c]];
             N.agg[c] = a;
-            cgi[a] = N.gi[c] >> 1; cgj[a] = N.gj[c] >> 1; cgt[a] = N.gt[c];
+            cgi[a] = N.gi[c] >> sh; cgj[a] = N.gj[c] >> sh; cgt[a] = N.gt[c];
          }
          n2 = ng;
       } else {
