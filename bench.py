@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--ml-smooth", type=int, default=3)
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--max-iters", type=int, default=20000)
-    ap.add_argument("--cpu-baseline-iters", type=int, default=100)
+    ap.add_argument("--cpu-baseline-iters", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="developer switch: run the distributed code path even with one rank")
     return ap.parse_args()
@@ -234,7 +234,7 @@ def main():
                   "relres_checked_with_torch": relres_check, "setup_s": t_setup, "generate_s": t_gen,
                   "levels": s.get_int("levels"), "device_MB": s.get_int("device_bytes") / 1e6,
                   "precond_apply_ms": pre_ms, "krylov_iteration_ms": it_ms},
-        "roofline": {"kernel": "csr_spmv_pipe_kernel<0>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "csr_spmv_pipe_kernel<0, double>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms},
     }

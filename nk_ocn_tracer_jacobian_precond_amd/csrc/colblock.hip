@@ -336,15 +336,16 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
          const int i = lane + u * NKP_WAVE;
          tr[u] = (i < nrows) ? rhs[(int64_t) R0 + i] : 0.0;
       }
-      for (int i0 = lane; i0 < cnt2; i0 += 20 * NKP_WAVE) {
-         double2 t[20];
+      constexpr int BATCH = sizeof (FT) == 4 ? 10 : 20;      // 16-byte loads per lane: one batch covers 8 x 64 x 5 factors
+      for (int i0 = lane; i0 < cnt2; i0 += BATCH * NKP_WAVE) {
+         double2 t[BATCH];
 #pragma unroll
-         for (int u = 0; u < 20; u++) {
+         for (int u = 0; u < BATCH; u++) {
             const int i = i0 + u * NKP_WAVE;
             t[u] = (i < cnt2) ? src[i] : make_double2 (0.0, 0.0);
          }
 #pragma unroll
-         for (int u = 0; u < 20; u++) {
+         for (int u = 0; u < BATCH; u++) {
             const int i = i0 + u * NKP_WAVE;
             if (i < cnt2) dst[i] = t[u];
          }
