@@ -76,8 +76,9 @@ typedef struct nkp_options {
    int reorth;           /* 0 = one classical Gram-Schmidt pass (default), 1 = two passes     */
    int ml_levels;        /* multilevel: max levels (0 = automatic)                            */
    int ml_smooth;        /* multilevel: smoothing sweeps per level per half-cycle             */
-   int basis_f32;        /* 1 (default): the Krylov basis V is stored in f32 for the Gram-Schmidt passes (the solution
-                            update uses the f64 Z vectors; the true residual is recomputed in f64 at every restart) */
+   int basis_f32;        /* 1: store the Krylov basis V in f32 for the Gram-Schmidt passes (the solution update uses
+                            the f64 Z vectors, the true residual is recomputed in f64 at every restart).  Default 0:
+                            with a single Gram-Schmidt pass the f32 basis can double the iteration count. */
    int reserved[6];
    /* multilevel, optional: grid position (i, j) of every water-column block, nblk entries each
     * (tracer_state_ind_to_i/_j at the block's first row, reference src/matrix.c:322-329).  With

@@ -24,18 +24,19 @@ ap.add_argument("--reorth", type=int, default=0)
 ap.add_argument("--solve", type=int, default=1)
 ap.add_argument("--verbose", type=int, default=0)
 ap.add_argument("--no-geo", type=int, default=0)
+ap.add_argument("--tracers", type=int, default=1)
 ap.add_argument("--ml-smooth", type=int, default=3)
 ap.add_argument("--ml-levels", type=int, default=0)
 ap.add_argument("--min-cos", type=float, default=0.3)
 a = ap.parse_args()
 imt, jmt, km = (int(t) for t in a.grid.split("x"))
 t0 = time.time()
-p = synth.generate(imt=imt, jmt=jmt, km=km, adv=a.adv, hmix=a.hmix, seed=0, min_cos=a.min_cos)
-blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
-ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+p = synth.generate(imt=imt, jmt=jmt, km=km, adv=a.adv, hmix=a.hmix, seed=0, min_cos=a.min_cos, coupled_tracer_cnt=a.tracers)
+blk = solver.column_blocks(p.col_start(), p.tracer_state_len, a.tracers)
+ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), a.tracers)
 tgen = time.time() - t0
 t0 = time.time()
-s = solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=None if a.no_geo else ci, col_j=None if a.no_geo else cj, restart=a.restart, max_iters=a.max_iters, rtol=a.rtol,
+s = solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=None if a.no_geo else ci, col_j=None if a.no_geo else cj, coupled_tracer_cnt=a.tracers, restart=a.restart, max_iters=a.max_iters, rtol=a.rtol,
                      precond=a.precond, krylov=a.krylov, reorth=a.reorth, verbose=a.verbose, ml_smooth=a.ml_smooth, ml_levels=a.ml_levels)
 tsetup = time.time() - t0
 res = dict(grid=a.grid, adv=a.adv, hmix=a.hmix, precond=a.precond, levels=s.get_int("levels"), ml_rows=s.get_int("ml_rows"), ml_nnz=s.get_int("ml_nnz"), n=p.flat_len, nnz=p.nnz, gen_s=round(tgen, 2), setup_s=round(tsetup, 3))
