@@ -305,3 +305,33 @@ def test_factor_only_call_and_edge_sizes(golden_by_name):
     with pytest.raises(solver.NkpError) as e:
         solver.NkpSolver(rp, np.arange(n, dtype=np.int32), np.ones(n), np.array([0, n], np.int32))
     assert e.value.code == -1 and "at most 128" in str(e.value)
+
+
+def test_cli_float32_tracer_with_time_record(tmp_path, golden_by_name):
+    """CESM tracer files are usually NC_FLOAT with a time record dimension: the CLI must convert on read
+    (libnetcdf semantics, reference src/file_io.c:286), solve, and write back converted, land untouched."""
+    from scipy.io import netcdf_file
+    g = golden_by_name("tri_12x10x6")
+    path = str(tmp_path / "hist.nc")
+    f = netcdf_file(path, "w", version=2)
+    f.createDimension("time", None)
+    f.createDimension("z_t", g.km)
+    f.createDimension("nlat", g.jmt)
+    f.createDimension("nlon", g.imt)
+    v = f.createVariable("IAGE", "f", ("time", "z_t", "nlat", "nlon"))
+    field32 = g.fields["IAGE"].astype(np.float32)
+    v[0] = field32
+    f.close()
+    r = subprocess.run([os.path.join(BIN, "solve_ABglobal"), "-v", "IAGE", g.matrix_path, path], capture_output=True, text=True,
+                       env=dict(os.environ, NKP_RTOL="1e-12"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = nc3.NcFile(path).get("IAGE")[0]
+    assert out.dtype == np.float32
+    ocean = np.zeros(field32.shape, bool)
+    ocean[g.ind_k, g.ind_j, g.ind_i] = True
+    assert np.array_equal(out[~ocean], field32[~ocean])
+    # the right-hand side the solver saw is the float32 field widened to double
+    b = field32.astype(np.float64)[g.ind_k, g.ind_j, g.ind_i]
+    x_ref, _ = ora.direct_solve(g.rowptr, g.colind, g.val, b)
+    x = out[g.ind_k, g.ind_j, g.ind_i].astype(np.float64)
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 5e-7          # float32 rounding of the stored result
