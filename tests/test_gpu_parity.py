@@ -335,3 +335,23 @@ def test_cli_float32_tracer_with_time_record(tmp_path, golden_by_name):
     x_ref, _ = ora.direct_solve(g.rowptr, g.colind, g.val, b)
     x = out[g.ind_k, g.ind_j, g.ind_i].astype(np.float64)
     assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 5e-7          # float32 rounding of the stored result
+
+
+@pytest.mark.parametrize("grid", [(24, 20, 10), (40, 46, 20)])
+def test_multilevel_cycle_matches_independent_restatement(grid, monkeypatch):
+    """z = V(3,3)-cycle(r) from the HIP hierarchy against tests/ml_reference.py (scipy, written from the
+    prose description).  f64 storage: agreement to rounding; default f32 storage: f32-level agreement."""
+    import ml_reference as mlr
+    p = synth.generate(imt=grid[0], jmt=grid[1], km=grid[2], adv="upwind3", hmix="isop", seed=2)
+    blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    colid = np.cumsum(p.ind_k == 0) - 1
+    levels = mlr.build(p.scipy_csr(), p.ind_i.astype(np.int64), p.ind_j.astype(np.int64), p.ind_k.astype(np.int64), colid)
+    r = np.random.default_rng(17).standard_normal(p.flat_len)
+    z_ref = mlr.cycle(levels, 0, r)
+    for f32, tol in ((0, 1e-9), (1, 2e-5)):
+        monkeypatch.setenv("NKP_ML_F32", str(f32))
+        with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, restart=4) as s:
+            assert s.get_int("levels") == len(levels)
+            z = s.precond_apply(r)
+        assert np.linalg.norm(z - z_ref) <= tol * np.linalg.norm(z_ref), (f32, np.linalg.norm(z - z_ref) / np.linalg.norm(z_ref))
