@@ -32,7 +32,11 @@ typedef struct {
 
 struct nc3_file {
    FILE *fp;
+   char *path;
    int writable;
+   int defining;                /* between nc3_create / nc3_redef and nc3_enddef */
+   int nvars_on_disk;           /* variables that already have data in the file */
+   int64_t *old_begin;          /* their offsets before the header grew */
    int version;                 /* 1, 2, 5 */
    uint64_t numrecs;
    int ndims, nvars, ngatts;
@@ -114,7 +118,8 @@ int nc3_close (nc3_file *f)
 {
    int status = NC3_NOERR;
    if (!f) return NC3_NOERR;
-   if (f->fp && fclose (f->fp)) status = NC3_EIO;
+   if (f->defining) status = nc3_enddef (f);
+   if (f->fp && fclose (f->fp) && !status) status = NC3_EIO;
    for (int i = 0; i < f->ndims; i++) free (f->dims[i].name);
    free (f->dims);
    for (int i = 0; i < f->nvars; i++) {
@@ -124,6 +129,8 @@ int nc3_close (nc3_file *f)
    }
    free (f->vars);
    free_atts (f->ngatts, f->gatts);
+   free (f->path);
+   free (f->old_begin);
    free (f);
    return status;
 }
@@ -143,6 +150,7 @@ int nc3_open (const char *path, int writable, nc3_file **out)
    nc3_file *f = (nc3_file *) calloc (1, sizeof (nc3_file));
    if (!f) { fclose (fp); return NC3_ENOMEM; }
    f->fp = fp;
+   f->path = strdup (path);
    f->writable = writable;
    f->version = magic[3];
    rd_t r = { fp, 1, f->version == 5 };
@@ -195,7 +203,8 @@ int nc3_open (const char *path, int writable, nc3_file **out)
          for (int d = v->is_record ? 1 : 0; d < v->ndims; d++) v->per_rec *= f->dims[v->dimids[d]].len;
       }
    }
-   if (!r.ok) { status = NC3_ENOTNC; goto fail; }
+   if (!r.ok || !f->path) { status = r.ok ? NC3_ENOMEM : NC3_ENOTNC; goto fail; }
+   f->nvars_on_disk = f->nvars;
 
    {  /* record stride: sum of the record variables' (padded) vsize, unpadded if there is only one */
       int nrec = 0;
@@ -230,6 +239,10 @@ const char *nc3_strerror (int status)
    case NC3_ENOTATT: return "NetCDF: Attribute not found";
    case NC3_EIO: return "NetCDF: I/O failure (open, seek, read or write)";
    case NC3_EPERM: return "NetCDF: Write to read only";
+   case NC3_ENAMEINUSE: return "NetCDF: String match to name in use";
+   case NC3_ENOTINDEFINE: return "NetCDF: Operation not allowed in data mode";
+   case NC3_EINDEFINE: return "NetCDF: Operation not allowed in define mode";
+   case NC3_EINVAL: return "NetCDF: Invalid Argument";
    default: return "NetCDF: Unknown error";
    }
 }
@@ -336,6 +349,7 @@ typedef enum { AS_DOUBLE, AS_INT } mem_t;
 static int transfer (nc3_file *f, int varid, void *mem, mem_t mt, int writing)
 {
    if (varid < 0 || varid >= f->nvars) return NC3_ENOTVAR;
+   if (f->defining) return NC3_EINDEFINE;
    if (writing && !f->writable) return NC3_EPERM;
    var_t *v = &f->vars[varid];
    int esz = type_size[v->type];
@@ -418,4 +432,363 @@ int nc3_get_att_double (nc3_file *f, int varid, const char *attname, double *val
          return NC3_NOERR;
       }
    return NC3_ENOTATT;
+}
+
+/* ---------------------------------------------------------------- define mode */
+
+int nc3_create (const char *path, int version, nc3_file **out)
+{
+   *out = NULL;
+   if (version != 1 && version != 2 && version != 5) return NC3_EINVAL;
+   /* like nc_create(NC_CLOBBER): the file exists (empty) from this point on */
+   FILE *fp = fopen (path, "w+b");
+   if (!fp) return NC3_EIO;
+   nc3_file *f = (nc3_file *) calloc (1, sizeof (nc3_file));
+   if (!f) { fclose (fp); return NC3_ENOMEM; }
+   f->fp = fp;
+   f->path = strdup (path);
+   if (!f->path) { nc3_close (f); return NC3_ENOMEM; }
+   f->writable = 1;
+   f->version = version;
+   f->defining = 1;
+   *out = f;
+   return NC3_NOERR;
+}
+
+int nc3_redef (nc3_file *f)
+{
+   if (!f->writable) return NC3_EPERM;
+   if (f->defining) return NC3_EINDEFINE;
+   free (f->old_begin);
+   f->old_begin = (int64_t *) malloc ((size_t) (f->nvars ? f->nvars : 1) * sizeof (int64_t));
+   if (!f->old_begin) return NC3_ENOMEM;
+   for (int i = 0; i < f->nvars; i++) f->old_begin[i] = f->vars[i].begin;
+   f->nvars_on_disk = f->nvars;
+   f->defining = 1;
+   return NC3_NOERR;
+}
+
+int nc3_inq_dimid (nc3_file *f, const char *name, int *dimid)
+{
+   for (int i = 0; i < f->ndims; i++)
+      if (strcmp (f->dims[i].name, name) == 0) { *dimid = i; return NC3_NOERR; }
+   return NC3_EBADDIM;
+}
+
+int nc3_def_dim (nc3_file *f, const char *name, size_t len, int *dimid)
+{
+   int id;
+   if (!f->defining) return NC3_ENOTINDEFINE;
+   if (len == 0) return NC3_EINVAL;                 /* no new record dimension */
+   if (f->version != 5 && (uint64_t) len > 0xFFFFFFFFull) return NC3_EINVAL;
+   if (nc3_inq_dimid (f, name, &id) == NC3_NOERR) return NC3_ENAMEINUSE;
+   dim_t *d = (dim_t *) realloc (f->dims, (size_t) (f->ndims + 1) * sizeof (dim_t));
+   if (!d) return NC3_ENOMEM;
+   f->dims = d;
+   d[f->ndims].name = strdup (name);
+   d[f->ndims].len = (uint64_t) len;
+   if (!d[f->ndims].name) return NC3_ENOMEM;
+   if (dimid) *dimid = f->ndims;
+   f->ndims++;
+   return NC3_NOERR;
+}
+
+int nc3_def_var (nc3_file *f, const char *name, int nc_type, int ndims, const int *dimids, int *varid)
+{
+   int id;
+   if (!f->defining) return NC3_ENOTINDEFINE;
+   if (nc_type < 1 || nc_type > 11 || ndims < 0 || ndims > 1024) return NC3_EINVAL;
+   if (f->version != 5 && nc_type > NC3_DOUBLE) return NC3_EINVAL;
+   if (nc3_inq_varid (f, name, &id) == NC3_NOERR) return NC3_ENAMEINUSE;
+   for (int d = 0; d < ndims; d++) {
+      if (dimids[d] < 0 || dimids[d] >= f->ndims) return NC3_EBADDIM;
+      if (f->dims[dimids[d]].len == 0) return NC3_EINVAL;          /* record variable */
+   }
+   var_t *vs = (var_t *) realloc (f->vars, (size_t) (f->nvars + 1) * sizeof (var_t));
+   if (!vs) return NC3_ENOMEM;
+   f->vars = vs;
+   var_t *v = &vs[f->nvars];
+   memset (v, 0, sizeof (*v));
+   v->name = strdup (name);
+   v->dimids = (int *) calloc (ndims ? (size_t) ndims : 1, sizeof (int));
+   if (!v->name || !v->dimids) { free (v->name); free (v->dimids); return NC3_ENOMEM; }
+   v->ndims = ndims;
+   v->type = nc_type;
+   v->per_rec = 1;
+   for (int d = 0; d < ndims; d++) { v->dimids[d] = dimids[d]; v->per_rec *= f->dims[dimids[d]].len; }
+   if (varid) *varid = f->nvars;
+   f->nvars++;
+   return NC3_NOERR;
+}
+
+static int put_att_raw (nc3_file *f, int varid, const char *name, int type, uint64_t n, unsigned char *raw)
+{
+   int *pn;
+   att_t **pa;
+   if (!f->defining) { free (raw); return NC3_ENOTINDEFINE; }
+   if (varid == -1) { pn = &f->ngatts; pa = &f->gatts; }
+   else if (varid >= 0 && varid < f->nvars) { pn = &f->vars[varid].natts; pa = &f->vars[varid].atts; }
+   else { free (raw); return NC3_ENOTVAR; }
+   for (int i = 0; i < *pn; i++)
+      if (strcmp ((*pa)[i].name, name) == 0) {              /* overwrite in place */
+         free ((*pa)[i].raw);
+         (*pa)[i].type = type;
+         (*pa)[i].n = n;
+         (*pa)[i].raw = raw;
+         return NC3_NOERR;
+      }
+   att_t *a = (att_t *) realloc (*pa, (size_t) (*pn + 1) * sizeof (att_t));
+   if (!a) { free (raw); return NC3_ENOMEM; }
+   *pa = a;
+   a[*pn].name = strdup (name);
+   a[*pn].type = type;
+   a[*pn].n = n;
+   a[*pn].raw = raw;
+   if (!a[*pn].name) { free (raw); return NC3_ENOMEM; }
+   (*pn)++;
+   return NC3_NOERR;
+}
+
+static unsigned char *att_buf (uint64_t nbytes)
+{
+   size_t padded = (size_t) ((nbytes + 3) & ~(uint64_t) 3);
+   return (unsigned char *) calloc (padded ? padded : 1, 1);
+}
+
+int nc3_put_att_text (nc3_file *f, int varid, const char *name, size_t len, const char *text)
+{
+   unsigned char *raw = att_buf (len);
+   if (!raw) return NC3_ENOMEM;
+   memcpy (raw, text, len);
+   return put_att_raw (f, varid, name, NC3_CHAR, len, raw);
+}
+
+int nc3_put_att_double (nc3_file *f, int varid, const char *name, int nc_type, size_t n, const double *vals)
+{
+   if (nc_type < 1 || nc_type > 11 || nc_type == NC3_CHAR) return NC3_EINVAL;
+   int esz = type_size[nc_type];
+   unsigned char *raw = att_buf ((uint64_t) n * (uint64_t) esz);
+   if (!raw) return NC3_ENOMEM;
+   int bad = 0;
+   for (size_t e = 0; e < n; e++) bad |= encode_double (raw + (size_t) esz * e, nc_type, vals[e]);
+   int status = put_att_raw (f, varid, name, nc_type, n, raw);
+   return status ? status : (bad ? NC3_ERANGE : NC3_NOERR);
+}
+
+int nc3_put_att_int (nc3_file *f, int varid, const char *name, int nc_type, size_t n, const int *vals)
+{
+   double *tmp = (double *) malloc ((n ? n : 1) * sizeof (double));
+   if (!tmp) return NC3_ENOMEM;
+   for (size_t e = 0; e < n; e++) tmp[e] = (double) vals[e];
+   int status = nc3_put_att_double (f, varid, name, nc_type, n, tmp);
+   free (tmp);
+   return status;
+}
+
+/* ---- header writer */
+
+typedef struct { FILE *fp; int ok; int wide; uint64_t bytes; } wr_t;
+
+static void wr_bytes (wr_t *w, const void *p, size_t n)
+{
+   if (w->fp && n && fwrite (p, 1, n, w->fp) != n) w->ok = 0;
+   w->bytes += n;
+}
+
+static void wr_u32 (wr_t *w, uint32_t u)
+{
+   unsigned char b[4];
+   store_be (b, 4, u);
+   wr_bytes (w, b, 4);
+}
+
+static void wr_u64 (wr_t *w, uint64_t u)
+{
+   unsigned char b[8];
+   store_be (b, 8, u);
+   wr_bytes (w, b, 8);
+}
+
+static void wr_nonneg (wr_t *w, uint64_t u) { if (w->wide) wr_u64 (w, u); else wr_u32 (w, (uint32_t) u); }
+
+static void wr_name (wr_t *w, const char *s)
+{
+   static const unsigned char zero[4] = { 0, 0, 0, 0 };
+   size_t n = strlen (s);
+   wr_nonneg (w, n);
+   wr_bytes (w, s, n);
+   wr_bytes (w, zero, (4 - (n & 3)) & 3);
+}
+
+static void wr_attlist (wr_t *w, int natts, const att_t *a)
+{
+   if (natts == 0) { wr_u32 (w, 0); wr_nonneg (w, 0); return; }
+   wr_u32 (w, TAG_ATT);
+   wr_nonneg (w, (uint64_t) natts);
+   for (int i = 0; i < natts; i++) {
+      wr_name (w, a[i].name);
+      wr_u32 (w, (uint32_t) a[i].type);
+      wr_nonneg (w, a[i].n);
+      uint64_t nbytes = a[i].n * (uint64_t) type_size[a[i].type];
+      wr_bytes (w, a[i].raw, (size_t) ((nbytes + 3) & ~(uint64_t) 3));
+   }
+}
+
+static uint64_t var_bytes (const var_t *v)
+{
+   uint64_t raw = v->per_rec * (uint64_t) type_size[v->type];
+   return (raw + 3) & ~(uint64_t) 3;
+}
+
+/* fp == NULL: size the header only */
+static uint64_t write_header (nc3_file *f, FILE *fp, int *ok)
+{
+   wr_t w = { fp, 1, f->version == 5, 0 };
+   unsigned char magic[4] = { 'C', 'D', 'F', (unsigned char) f->version };
+   wr_bytes (&w, magic, 4);
+   wr_nonneg (&w, f->numrecs);
+   if (f->ndims == 0) { wr_u32 (&w, 0); wr_nonneg (&w, 0); }
+   else {
+      wr_u32 (&w, TAG_DIM);
+      wr_nonneg (&w, (uint64_t) f->ndims);
+      for (int i = 0; i < f->ndims; i++) { wr_name (&w, f->dims[i].name); wr_nonneg (&w, f->dims[i].len); }
+   }
+   wr_attlist (&w, f->ngatts, f->gatts);
+   if (f->nvars == 0) { wr_u32 (&w, 0); wr_nonneg (&w, 0); }
+   else {
+      wr_u32 (&w, TAG_VAR);
+      wr_nonneg (&w, (uint64_t) f->nvars);
+      for (int i = 0; i < f->nvars; i++) {
+         const var_t *v = &f->vars[i];
+         wr_name (&w, v->name);
+         wr_nonneg (&w, (uint64_t) v->ndims);
+         for (int d = 0; d < v->ndims; d++) wr_nonneg (&w, (uint64_t) v->dimids[d]);
+         wr_attlist (&w, v->natts, v->atts);
+         wr_u32 (&w, (uint32_t) v->type);
+         uint64_t vs = var_bytes (v);
+         if (!w.wide && vs > 0xFFFFFFFFull) vs = 0xFFFFFFFFull;
+         wr_nonneg (&w, vs);
+         if (f->version == 1) wr_u32 (&w, (uint32_t) v->begin); else wr_u64 (&w, (uint64_t) v->begin);
+      }
+   }
+   if (ok) *ok = w.ok;
+   return w.bytes;
+}
+
+static void default_fill (int type, unsigned char *p)
+{
+   switch (type) {
+   case NC3_BYTE: p[0] = (unsigned char) (int8_t) -127; break;
+   case NC3_CHAR: p[0] = 0; break;
+   case NC3_SHORT: store_be (p, 2, (uint64_t) (uint16_t) (int16_t) -32767); break;
+   case NC3_INT: store_be (p, 4, (uint64_t) (uint32_t) (int32_t) -2147483647); break;
+   case NC3_FLOAT: { float x = 9.9692099683868690e+36f; uint32_t u; memcpy (&u, &x, 4); store_be (p, 4, u); break; }
+   case NC3_DOUBLE: { double x = 9.9692099683868690e+36; uint64_t u; memcpy (&u, &x, 8); store_be (p, 8, u); break; }
+   case NC3_UBYTE: p[0] = 255; break;
+   case NC3_USHORT: store_be (p, 2, 65535u); break;
+   case NC3_UINT: store_be (p, 4, 4294967295u); break;
+   case NC3_INT64: store_be (p, 8, (uint64_t) (int64_t) -9223372036854775806LL); break;
+   case NC3_UINT64: store_be (p, 8, 18446744073709551614ULL); break;
+   }
+}
+
+static int fill_var (FILE *fp, const var_t *v)
+{
+   int esz = type_size[v->type];
+   unsigned char fv[8];
+   default_fill (v->type, fv);
+   for (int i = 0; i < v->natts; i++)
+      if (strcmp (v->atts[i].name, "_FillValue") == 0 && v->atts[i].type == v->type && v->atts[i].n >= 1)
+         memcpy (fv, v->atts[i].raw, (size_t) esz);
+   size_t chunk = CHUNK_ELEMS;
+   uint64_t total = v->per_rec;
+   if (total < chunk) chunk = (size_t) (total ? total : 1);
+   unsigned char *buf = (unsigned char *) malloc (chunk * (size_t) esz);
+   if (!buf) return NC3_ENOMEM;
+   for (size_t e = 0; e < chunk; e++) memcpy (buf + e * (size_t) esz, fv, (size_t) esz);
+   uint64_t left = total;
+   int status = NC3_NOERR;
+   while (left && !status) {
+      size_t m = left < chunk ? (size_t) left : chunk;
+      if (fwrite (buf, (size_t) esz, m, fp) != m) status = NC3_EIO;
+      left -= m;
+   }
+   free (buf);
+   uint64_t pad = var_bytes (v) - total * (uint64_t) esz;
+   static const unsigned char zero[4] = { 0, 0, 0, 0 };
+   if (!status && pad && fwrite (zero, 1, (size_t) pad, fp) != pad) status = NC3_EIO;
+   return status;
+}
+
+static int copy_bytes (FILE *src, int64_t src_off, FILE *dst, uint64_t nbytes)
+{
+   size_t chunk = (size_t) 8 << 20;
+   if (nbytes < chunk) chunk = (size_t) (nbytes ? nbytes : 1);
+   unsigned char *buf = (unsigned char *) malloc (chunk);
+   if (!buf) return NC3_ENOMEM;
+   int status = NC3_NOERR;
+   if (fseeko (src, (off_t) src_off, SEEK_SET)) status = NC3_EIO;
+   while (nbytes && !status) {
+      size_t m = nbytes < chunk ? (size_t) nbytes : chunk;
+      if (fread (buf, 1, m, src) != m || fwrite (buf, 1, m, dst) != m) status = NC3_EIO;
+      nbytes -= m;
+   }
+   free (buf);
+   return status;
+}
+
+int nc3_enddef (nc3_file *f)
+{
+   if (!f->defining) return NC3_ENOTINDEFINE;
+
+   /* layout: header, fixed-size variables in definition order, then the record section */
+   uint64_t off = (write_header (f, NULL, NULL) + 3) & ~(uint64_t) 3;
+   int64_t old_rec_begin = -1;
+   for (int i = 0; i < f->nvars; i++)
+      if (!f->vars[i].is_record) { f->vars[i].begin = (int64_t) off; off += var_bytes (&f->vars[i]); }
+   uint64_t rec_begin = off;
+   for (int i = 0; i < f->nvars; i++)
+      if (f->vars[i].is_record) {
+         if (old_rec_begin < 0 || f->old_begin[i] < old_rec_begin) old_rec_begin = f->old_begin[i];
+         f->vars[i].begin = (int64_t) off;
+         off += (f->recsize == f->vars[i].per_rec * (uint64_t) type_size[f->vars[i].type]) ? f->recsize : var_bytes (&f->vars[i]);
+      }
+   if (f->version == 1)
+      for (int i = 0; i < f->nvars; i++)
+         if ((uint64_t) f->vars[i].begin > 0x7FFFFFFFull) return NC3_EINVAL;
+
+   /* write the new image beside the old one, then swap */
+   size_t plen = strlen (f->path);
+   char *tmp = (char *) malloc (plen + 16);
+   if (!tmp) return NC3_ENOMEM;
+   snprintf (tmp, plen + 16, "%s.nc3tmp", f->path);
+   FILE *out = fopen (tmp, "w+b");
+   if (!out) { free (tmp); return NC3_EIO; }
+   int ok = 1;
+   int status = NC3_NOERR;
+   uint64_t hbytes = write_header (f, out, &ok);
+   if (!ok) status = NC3_EIO;
+   static const unsigned char zero[4] = { 0, 0, 0, 0 };
+   if (!status && (hbytes & 3) && fwrite (zero, 1, 4 - (hbytes & 3), out) != 4 - (hbytes & 3)) status = NC3_EIO;
+   for (int i = 0; i < f->nvars && !status; i++) {
+      const var_t *v = &f->vars[i];
+      if (v->is_record) continue;
+      if (i < f->nvars_on_disk && f->old_begin) status = copy_bytes (f->fp, f->old_begin[i], out, var_bytes (v));
+      else status = fill_var (out, v);
+   }
+   if (!status && old_rec_begin >= 0 && f->numrecs) {
+      (void) rec_begin;
+      status = copy_bytes (f->fp, old_rec_begin, out, f->numrecs * f->recsize);
+   }
+   if (!status && fflush (out)) status = NC3_EIO;
+   if (status) { fclose (out); remove (tmp); free (tmp); return status; }
+   fclose (f->fp);
+   f->fp = out;
+   if (rename (tmp, f->path)) status = NC3_EIO;
+   free (tmp);
+   free (f->old_begin);
+   f->old_begin = NULL;
+   f->nvars_on_disk = f->nvars;
+   f->defining = 0;
+   return status;
 }

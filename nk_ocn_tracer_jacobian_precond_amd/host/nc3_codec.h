@@ -28,7 +28,11 @@ enum {
    NC3_EHDF5 = -101,      /* netCDF-4/HDF5 container: unsupported here */
    NC3_ENOTATT = -43,
    NC3_EIO = -68,         /* open/seek/short read/short write */
-   NC3_EPERM = -37        /* write to a file opened read-only */
+   NC3_EPERM = -37,       /* write to a file opened read-only */
+   NC3_ENAMEINUSE = -42,  /* dimension / variable name already defined */
+   NC3_ENOTINDEFINE = -38,/* definition call outside define mode */
+   NC3_EINDEFINE = -39,   /* data call while in define mode */
+   NC3_EINVAL = -36
 };
 
 enum { NC3_BYTE = 1, NC3_CHAR, NC3_SHORT, NC3_INT, NC3_FLOAT, NC3_DOUBLE,
@@ -54,6 +58,22 @@ int nc3_put_var_double (nc3_file *f, int varid, const double *in);
 int nc3_put_var_int (nc3_file *f, int varid, const int *in);
 /* numeric attribute of a variable (varid -1 = global), first element, as double */
 int nc3_get_att_double (nc3_file *f, int varid, const char *attname, double *val);
+
+/* ---- define mode: the calls the reference's writers make (reference src/grid.c:234-296,
+ * src/matrix.c:283-333, 3862-3895): create a 64-bit-offset file or re-open one with nc_redef,
+ * add dimensions, variables and attributes, leave define mode (nc_close does it implicitly,
+ * as in libnetcdf).  Leaving define mode lays the variables out in definition order and moves
+ * existing data behind the grown header; new variables are pre-filled with the default fill
+ * values (libnetcdf's NC_FILL default).  New record variables are not supported. */
+int nc3_create (const char *path, int version /* 1, 2 or 5 */, nc3_file **out);
+int nc3_redef (nc3_file *f);
+int nc3_enddef (nc3_file *f);
+int nc3_def_dim (nc3_file *f, const char *name, size_t len, int *dimid);
+int nc3_inq_dimid (nc3_file *f, const char *name, int *dimid);
+int nc3_def_var (nc3_file *f, const char *name, int nc_type, int ndims, const int *dimids, int *varid);
+int nc3_put_att_text (nc3_file *f, int varid, const char *name, size_t len, const char *text);
+int nc3_put_att_int (nc3_file *f, int varid, const char *name, int nc_type, size_t n, const int *vals);
+int nc3_put_att_double (nc3_file *f, int varid, const char *name, int nc_type, size_t n, const double *vals);
 
 #ifdef __cplusplus
 }

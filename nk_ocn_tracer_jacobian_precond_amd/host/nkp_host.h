@@ -8,8 +8,9 @@
  *   memory    : reference src/memory.h:6-14    (one contiguous slab behind a pointer ladder)
  *   misc      : reference src/misc.h:6-8
  *   globals   : reference src/globals.h:6-7
- *   grid dims : reference src/grid.h:6,27-29   (get_grid_dims only; the solvers need nothing else)
- *   matrix    : reference src/matrix.h:8,9,12,13,19-24,58-68 (readers + index maps only)
+ *   grid      : reference src/grid.h:6-31      (dims for the solvers; loader + writer for gen_A)
+ *   matrix    : reference src/matrix.h:6-81    (readers + index maps for the solvers; generator,
+ *               option types/globals and writers for gen_A)
  *
  * Pure C, no GPU dependency: this library loads on any host (CPU tests use it directly).
  */
@@ -68,6 +69,20 @@ extern int jmt;
 extern int km;
 int get_grid_dims (char *fname);
 
+/* ---- grid info for the matrix generator (reference src/grid.c:90-330, src/grid.h:15-31) -- */
+extern char *circ_fname;
+extern char *reg_fname;
+extern double *z_t;
+extern double *dz;
+extern double **TLONG;
+extern double **TLAT;
+extern int **KMT;
+extern int **KMU;
+extern double **TAREA;
+int get_grid_info (char *circ_fname, char *reg_fname);
+int put_grid_info (char *fname);
+void free_grid_info (void);
+
 /* ---- matrix + index maps (reference src/matrix.c:373-464, 3943-4070) ------------------- */
 typedef struct { int i; int j; int k; } int3;
 
@@ -85,6 +100,36 @@ int get_ind_maps (char *fname);
 void free_ind_maps (void);
 int get_sparse_matrix (char *fname);
 void free_sparse_matrix (void);
+
+/* ---- matrix generator (reference src/matrix.h:6-9,26-56,70-81; src/matrix.c:163-369, 466-3939) */
+typedef enum { adv_none, adv_donor, adv_cent, adv_upwind3 } adv_opt_t;
+typedef enum { hmix_none, hmix_const, hmix_hor_file, hmix_isop_file } hmix_opt_t;
+typedef enum { vmix_none, vmix_const, vmix_file, vmix_matrix_file } vmix_opt_t;
+typedef enum { sink_none, sink_const, sink_const_shallow, sink_file, sink_generic_tracer } sink_opt_t;
+typedef struct {
+   sink_opt_t sink_opt;
+   double sink_rate;            /* loss rate, 1/yr */
+   double sink_depth;           /* depth threshold of sink_const_shallow, cm (as z_t) */
+   char *sink_field_name;
+   char *sink_generic_tracer_name;
+   int sink_generic_tracer_depends_layer_cnt;
+   char *pv_field_name;
+   char *d_SF_d_TRACER_field_name;
+} per_tracer_opt_t;
+typedef enum { coupled_tracer_none, coupled_tracer_OCMIP_BGC_PO4_DOP, coupled_tracer_DIC_SHADOW_ALK_SHADOW } coupled_tracer_opt_t;
+
+extern adv_opt_t adv_opt;
+extern int l_adv_enforce_divfree;
+extern hmix_opt_t hmix_opt;
+extern vmix_opt_t vmix_opt;
+extern char *tracer_fname;
+extern per_tracer_opt_t *per_tracer_opt;
+extern coupled_tracer_opt_t coupled_tracer_opt;
+
+int gen_ind_maps (void);
+int put_ind_maps (char *fname);
+int gen_sparse_matrix (double day_cnt);
+int put_sparse_matrix (char *fname);
 
 /* ---- additions of this build (no reference counterpart) ------------------------------- */
 

@@ -355,3 +355,57 @@ def test_multilevel_cycle_matches_independent_restatement(grid, monkeypatch):
             assert s.get_int("levels") == len(levels)
             z = s.precond_apply(r)
         assert np.linalg.norm(z - z_ref) <= tol * np.linalg.norm(z_ref), (f32, np.linalg.norm(z - z_ref) / np.linalg.norm(z_ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("job", ["shipped", "coupled_pair"])
+def test_gen_A_to_solve_pipeline(tmp_path, job):
+    """The reference's whole chain (test/test_gen_A.csh -> test/test_solve_ABglobal.csh): circulation file
+    -> bin/gen_A -> matrix file -> bin/solve_ABglobal on the GPU; the solution is checked against SuperLU
+    (scipy) on the CSR read back from the generated file."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from nk_ocn_tracer_jacobian_precond_amd import circ
+
+    F, fills = circ.make_circulation(24, 20, 12, seed=2)
+    cpath, mpath, tpath = str(tmp_path / "circ.nc"), str(tmp_path / "matrix.nc"), str(tmp_path / "tracers.nc")
+    circ.write_circ_file(cpath, F, fills, nc_type="float32")
+    opt = f"circ_fname {cpath}\nadv_type upwind3\nhmix_type isop_file\nvmix_type file\nsink_type const_shallow 365.0 10.0e2\n"
+    names = ["IAGE"]
+    if job == "coupled_pair":
+        T = circ.make_tracer_sources(F, seed=2)
+        circ.write_tracer_source_file(str(tmp_path / "src.nc"), F, T)
+        opt = (f"circ_fname {cpath}\ntracer_fname {tmp_path / 'src.nc'}\nadv_type cent\nhmix_type const\nvmix_type file\n"
+               "coupled_tracer_cnt 2\ncoupled_tracer_type OCMIP_BGC_PO4_DOP\nsink_type const 0.5\ntracer_ind 1\nsink_type const_shallow 2.0 3.0e3\n")
+        names = ["OCMIP_BGC_PO4", "OCMIP_BGC_DOP"]
+    (tmp_path / "gen_A.opt").write_text(opt)
+    r = subprocess.run([os.path.join(BIN, "gen_A"), "-o", str(tmp_path / "gen_A.opt"), mpath], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+    m = nc3.NcFile(mpath)
+    rp, ci, val = m.get("rowptr"), m.get("colind"), m.get("nzval_row_wise")
+    ii, jj, kk = (m.get(f"tracer_state_ind_to_{c}") for c in "ijk")
+    n, tsl = len(rp) - 1, len(ii)
+    rng = np.random.default_rng(4)
+    fields = {}
+    for nm in names:
+        f = np.full((12, 20, 24), synth.FILL_DOUBLE)
+        f[kk, jj, ii] = rng.standard_normal(tsl)
+        fields[nm] = f
+    dims = {"nlon": 24, "nlat": 20, "z_t": 12}
+    nc3.write(tpath, dims, [(nm, ["z_t", "nlat", "nlon"], f, {"_FillValue": np.float64(synth.FILL_DOUBLE)}) for nm, f in fields.items()])
+    b = np.concatenate([fields[nm][kk, jj, ii] for nm in names])
+
+    env = dict(os.environ, NKP_RTOL="1e-12")
+    r = subprocess.run([os.path.join(BIN, "solve_ABglobal"), "-D1", "-v", ",".join(names), mpath, tpath], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr + r.stdout
+    out = nc3.NcFile(tpath)
+    x = np.concatenate([out.get(nm)[kk, jj, ii] for nm in names])
+    A = sp.csr_matrix((val, ci, rp), shape=(n, n))
+    assert np.linalg.norm(b - A @ x) / np.linalg.norm(b) <= 1e-10
+    x_ref = spla.splu(A.tocsc()).solve(b)
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 1e-8
+    land = np.ones((12, 20, 24), bool)
+    land[kk, jj, ii] = False
+    for nm in names:
+        assert np.array_equal(out.get(nm)[land], fields[nm][land])
