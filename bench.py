@@ -25,7 +25,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0               # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MEASURED_COPY_GBS = 6290.0          # measured float4 copy on the same part (same guide, table row "HBM3E peak BW")
 
 
 def parse():
@@ -236,7 +237,10 @@ def main():
                   "precond_apply_ms": pre_ms, "krylov_iteration_ms": it_ms},
         "roofline": {"kernel": "csr_spmv_pipe_kernel<0, double>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms},
+                     "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms,
+                     # context only: the guide's measured float4-copy ceiling (MI355X_MICROARCH.md: 6.29 TB/s)
+                     "measured_copy_ceiling": MEASURED_COPY_GBS, "frac_of_copy_ceiling": achieved / MEASURED_COPY_GBS,
+                     "hbm_traffic_rate": (traffic / spmv_ms / 1e6) if traffic else None},
     }
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(p, blk, int(round(float(np.mean(iters)))), a.cpu_baseline_iters)

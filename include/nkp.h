@@ -106,7 +106,11 @@ int nkp_create (nkp_solver **out, const nkp_options *opt, int64_t n, int64_t nnz
 /* Solve nrhs systems; b (host, column-major, leading dimension ldb >= n) is overwritten by x
  * when the return code is NKP_OK or NKP_NOT_CONVERGED.  berr[r] receives the componentwise
  * backward error max_i |b-Ax|_i / (|A||x|+|b|)_i like SuperLU's; iters/relres per rhs.
- * Any of berr/iters/relres may be NULL. */
+ * Any of berr/iters/relres may be NULL.
+ * Converged (NKP_OK) means ||b-Ax||/||b|| <= rtol (or <= atol absolute), or -- when rounding stops the
+ * residual from falling further -- a componentwise backward error <= max (1e-14, rtol / 100), which is
+ * the accuracy measure the reference itself reports (berr, src/solve_ABglobal.c:396-398).  A solve that stalls above
+ * both returns NKP_NOT_CONVERGED after a few restart cycles instead of running to max_iters. */
 int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t ldb,
                double *berr, int *iters, double *relres);
 

