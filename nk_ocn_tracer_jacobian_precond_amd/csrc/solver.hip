@@ -306,6 +306,23 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
 
    if (opt.precond == NKP_PRECOND_MULTILEVEL) {
       char err[256] = "";
+      // developer switch: build the hierarchy without the couplings between tracers, i.e. exactly the
+      // preconditioner a tracer-per-rank partition applies (one rank-local hierarchy per tracer), to measure its
+      // iteration count on one GPU
+      std::vector<int32_t> f_rowptr, f_colind;
+      std::vector<double> f_val;
+      if (getenv ("NKP_ML_DROP_INTERTRACER") && atoi (getenv ("NKP_ML_DROP_INTERTRACER")) && coupled_tracer_cnt > 1) {
+         const int64_t tsl = n / coupled_tracer_cnt;
+         f_rowptr.assign ((size_t) n + 1, 0);
+         for (int64_t i = 0; i < n; i++) {
+            for (int32_t e = rowptr[i]; e < rowptr[i + 1]; e++)
+               if (colind[e] / tsl == i / tsl) { f_colind.push_back (colind[e]); f_val.push_back (val[e]); }
+            f_rowptr[(size_t) i + 1] = (int32_t) f_colind.size ();
+         }
+         rowptr = f_rowptr.data ();
+         colind = f_colind.data ();
+         val = f_val.data ();
+      }
       const int mrc = ml_setup (s->ml, n, rowptr, colind, val, blk_start, nblk, blk_default.empty () ? opt.col_i : nullptr, blk_default.empty () ? opt.col_j : nullptr, coupled_tracer_cnt, opt.ml_levels, opt.ml_smooth, 1500, opt.verbose, opt.rank, s->stream, err, sizeof err);
       if (mrc != 0) {
          rc = fail (mrc, "nkp_create: %s", err);

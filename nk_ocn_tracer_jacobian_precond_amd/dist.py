@@ -52,6 +52,20 @@ def local_slice(rowptr, colind, val, blk_start, starts, rank, col_i=None, col_j=
     return out
 
 
+def tracer_slice(p1, rank, nranks):
+    """One tracer per rank (weak scaling over coupled tracers, BASELINE config "1 degree x 4 tracers"): rows of
+    tracer `rank` of the `nranks`-tracer coupled problem on the single-tracer synthetic problem p1.  Rows are
+    tracer-major (reference src/matrix.c:778-784), so this IS the reference's contiguous row-block partition
+    (src/solve_ABdist.c:141-144) with nranks == coupled_tracer_cnt.  Returns (loc, starts, n_global)."""
+    from . import synth
+    tsl = p1.tracer_state_len
+    rp, ci, v = synth.tracer_rows(p1, rank, nranks)
+    blk = _solver.column_blocks(p1.col_start(), tsl, 1)
+    col_i, col_j = _solver.column_coords(p1.ind_i, p1.ind_j, p1.col_start(), 1)
+    loc = dict(rowptr=rp, colind=ci, val=v, blk_start=blk, fst_row=rank * tsl, m_loc=tsl, col_i=col_i, col_j=col_j)
+    return loc, np.arange(nranks + 1, dtype=np.int64) * tsl, nranks * tsl
+
+
 def plan_host(rowptr_loc, colind_glob, starts, rank):
     """nkp_dist_plan_host: remapped columns, needed off-rank rows, per-owner counts (no GPU needed)."""
     lib = _solver.load_library()

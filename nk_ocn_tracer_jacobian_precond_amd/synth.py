@@ -410,3 +410,47 @@ def write_tracer_file(p: SynthProblem, path, fields, version=2, nc_type="float64
 def flatten(p: SynthProblem, fields_list):
     """B[t*tsl + s] = field_t[k_s][j_s][i_s]  (reference src/solve_ABglobal.c:184-191)."""
     return np.concatenate([f[p.ind_k, p.ind_j, p.ind_i] for f in fields_list])
+
+
+def tracer_rows(p1: SynthProblem, t, cnt):
+    """Rows of tracer `t` of the `cnt`-tracer coupled problem built on the single-tracer problem `p1`
+    (same recipe as generate(coupled_tracer_cnt=cnt): per-tracer decay on the diagonal, same-cell
+    coupling entries to every other tracer) -- without ever forming the other tracers' rows.
+
+    Returns (rowptr_local, colind_global, val): what one rank of a tracer-per-rank partition owns
+    (reference src/matrix.c:778-784: rows are tracer-major, so tracer t is the contiguous row block
+    [t * tracer_state_len, (t + 1) * tracer_state_len)).
+    """
+    if p1.coupled_tracer_cnt != 1:
+        raise ValueError("p1 must be a single-tracer problem")
+    tsl = p1.tracer_state_len
+    if cnt == 1:
+        return p1.rowptr.copy(), p1.colind.copy(), p1.nzval.copy()
+    year_cnt = p1.meta["day_cnt"] / 365.0
+    rp = p1.rowptr.astype(np.int64)
+    length = np.diff(rp)
+    rows = np.repeat(np.arange(tsl, dtype=np.int64), length)
+    v = p1.nzval.copy()
+    diag = np.flatnonzero(p1.colind == rows)
+    if diag.size != tsl:
+        raise ValueError("single-tracer matrix lacks a diagonal entry")
+    v[diag] += -year_cnt * 0.05 * t
+    depth_w = np.exp(-p1.z_t[p1.ind_k] / 3.0e4)
+    others = [t2 for t2 in range(cnt) if t2 != t]
+    rates = {}
+    for t2 in others:
+        rates[t2] = year_cnt * (2.0 if (t2 == (t - 1) % cnt) else 0.25) * depth_w
+        v[diag] -= rates[t2]
+    new_rp = np.zeros(tsl + 1, np.int64)
+    np.cumsum(length + (cnt - 1), out=new_rp[1:])
+    ci = np.empty(new_rp[-1], np.int32)
+    val = np.empty(new_rp[-1], np.float64)
+    cell = np.arange(tsl, dtype=np.int64)
+    for m, t2 in enumerate(others):                      # t2 < t sorts before the tracer's own columns, t2 > t after
+        pos = new_rp[:-1] + (m if t2 < t else m + length)
+        ci[pos] = t2 * tsl + cell
+        val[pos] = rates[t2]
+    own = new_rp[:-1][rows] + t + (np.arange(rp[-1], dtype=np.int64) - rp[:-1][rows])
+    ci[own] = p1.colind.astype(np.int64) + t * tsl
+    val[own] = v
+    return new_rp.astype(np.int32), ci, val

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--grid", default="24x20x10")
     ap.add_argument("--restart", type=int, default=60)
     ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--partition", default="bands", help="bands: latitude bands of one matrix; tracers: one coupled tracer per rank")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -36,8 +37,12 @@ def main():
     n = p.flat_len
     blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
     ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
-    starts = nd.snap_partition(blk, world)
-    loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, rank, ci, cj)
+    if a.partition == "tracers":
+        loc, starts, n = nd.tracer_slice(p, rank, world)
+        p = synth.generate(imt=imt, jmt=jmt, km=km, adv="upwind3", hmix="isop", seed=a.seed, coupled_tracer_cnt=world)   # global matrix: checks only
+    else:
+        starts = nd.snap_partition(blk, world)
+        loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, rank, ci, cj)
     f, m = loc["fst_row"], loc["m_loc"]
     rng = np.random.default_rng(3)
     xg = rng.standard_normal(n)

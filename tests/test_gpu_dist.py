@@ -17,6 +17,18 @@ def test_distributed_solve(tmp_path, world):
     assert len({r["iters"] for r in res}) == 1                  # every rank took the same global decisions
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_solve_one_tracer_per_rank(tmp_path, world):
+    """Weak-scaling layout: rank t holds tracer t of a `world`-tracer coupled system (its preconditioner ignores the
+    coupling to the other tracers, the Krylov operator does not)."""
+    res = launch(world, "gpu-solve", str(tmp_path / "solve_t"), extra=("--grid", "40x46x20", "--partition", "tracers"))
+    assert all(r["spmv_bit_exact"] for r in res), res
+    assert all(not r["comm_errors"] for r in res), res
+    assert all(r["status"] == 0 and r["relres"] <= 1e-10 for r in res), res
+    assert res[0]["relres_checked"] <= 1.1e-10
+    assert len({r["iters"] for r in res}) == 1
+
+
 def test_solve_ABdist_cli_with_builtin_rccl(tmp_path, golden_by_name):
     """The executable's distributed entry point with the library's own RCCL communicator (one rank: the
     multi-rank launch needs one GPU per rank, which the test box does not have)."""
