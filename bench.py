@@ -8,7 +8,13 @@ Workload at N=1: the 1 degree x 60 level single-tracer Jacobian BASELINE.json's 
 on (configs[2]); synthetic, built by nk_ocn_tracer_jacobian_precond_amd.synth with the stencil
 of the reference's shipped job (upwind3 + isop + vmix + shallow sink, test/test_gen_A.csh:22-23).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--grid IxJxK] [--adv ..] [--hmix ..]
+N > 1 (one process per GPU, launched by torch.distributed.run, RCCL through torch.distributed):
+weak scaling -- the N-tracer coupled 1 degree system of BASELINE's "1 degree x 4 tracers, row-partitioned
+across 8 GPUs" configuration; rows are tracer-major, so the reference's contiguous row-block rule gives
+rank t tracer t (per-GPU work = the N=1 workload; halo alltoallv + allreduce per iteration).
+`--multi-gpu strong` instead splits the single-tracer matrix into N latitude bands.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--grid IxJxK] [--adv ..] [--hmix ..] [--multi-gpu weak|strong]
 
 Prints ONE JSON line on rank 0.  value = unknowns solved per second over the whole job.
 """

@@ -16,9 +16,20 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "nc3_codec.h"
 #include "nkp_host.h"
+
+/* where the time goes, reported at dbg_lvl >= 1: field reads (I/O + type conversion) against row passes */
+static double t_read = 0.0, t_rows = 0.0;
+
+static double now_s (void)
+{
+   struct timespec ts;
+   clock_gettime (CLOCK_MONOTONIC, &ts);
+   return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
 
 adv_opt_t adv_opt = adv_cent;
 int l_adv_enforce_divfree = 1;
@@ -349,6 +360,7 @@ static double ***read_3d (char *fname, char *name, int want_fv)
 {
    double ***F = malloc_3d_double (km, jmt, imt);
    double fv;
+   double t0 = now_s ();
 
    if (F == NULL) {
       fprintf (stderr, "(%d) malloc failed for %s\n", iam, name);
@@ -370,6 +382,7 @@ static double ***read_3d (char *fname, char *name, int want_fv)
          if (p[e] == fv)
             p[e] = 0.0;
    }
+   t_read += now_s () - t0;
    return F;
 }
 
@@ -415,22 +428,26 @@ typedef void (*row_term) (const row_ctx *R, double *v, void *arg);
 
 static void for_rows (row_term term, void *arg)
 {
+   double t0 = now_s ();
 #pragma omp parallel for schedule(static)
    for (int row = 0; row < flat_len; row++) {
       row_ctx R;
       row_layout (row / tracer_state_len, row % tracer_state_len, &R);
       term (&R, nzval_row_wise + rowptr[row], arg);
    }
+   t_rows += now_s () - t0;
 }
 
 static void for_rows_of_tracer (int t, row_term term, void *arg)
 {
+   double t0 = now_s ();
 #pragma omp parallel for schedule(static)
    for (int s = 0; s < tracer_state_len; s++) {
       row_ctx R;
       row_layout (t, s, &R);
       term (&R, nzval_row_wise + rowptr[t * tracer_state_len + s], arg);
    }
+   t_rows += now_s () - t0;
 }
 
 #define HAS(c) (R->slot[c] >= 0)
@@ -1038,8 +1055,12 @@ static int add_hmix_isop_file (void)
             }
             if (dbg_lvl)
                printf ("(%d) %s: reading %s from %s\n", iam, subname, IRF_name, circ_fname);
-            if (get_var_3d_double (circ_fname, IRF_name, A.IRF))
-               return 1;
+            {
+               double t0 = now_s ();
+               if (get_var_3d_double (circ_fname, IRF_name, A.IRF))
+                  return 1;
+               t_read += now_s () - t0;
+            }
             for_rows (term_hmix_isop, &A);
          }
    free_3d_double (A.IRF);
@@ -1593,10 +1614,16 @@ int gen_sparse_matrix (double day_cnt)
       return 1;
    if (add_coupled_tracers (1))
       return 1;
-   sum_dup_vals ();
-   strip_matrix_zeros ();
-   check_matrix_diag ();
-   sort_cols_all_rows ();
+   {
+      double t0 = now_s ();
+      sum_dup_vals ();
+      strip_matrix_zeros ();
+      check_matrix_diag ();
+      sort_cols_all_rows ();
+      if (dbg_lvl)
+         printf ("(%d) %s: %.2f s reading fields, %.2f s in row passes, %.2f s folding / stripping / sorting\n", iam, subname,
+                 t_read, t_rows, now_s () - t0);
+   }
    trace ("exiting", subname);
    return 0;
 }
@@ -1614,6 +1641,7 @@ int put_sparse_matrix (char *fname)
       return handle_nc_error (subname, "nc_open", fname, status);
    if ((status = nc3_redef (f)))
       return handle_nc_error (subname, "nc_redef", fname, status);
+   nc3_set_fill (f, 0);      /* every new variable is written in full below: skip the GB-sized pre-fill */
    if ((status = nc3_def_dim (f, "nnz", (size_t) nnz, &nnz_dimid)))
       return handle_nc_error (subname, "nc_def_dim", "nnz", status);
    if ((status = nc3_def_dim (f, "flat_len_p1", (size_t) flat_len + 1, &flat_len_p1_dimid)))

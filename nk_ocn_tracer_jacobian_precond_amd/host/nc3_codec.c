@@ -35,6 +35,7 @@ struct nc3_file {
    char *path;
    int writable;
    int defining;                /* between nc3_create / nc3_redef and nc3_enddef */
+   int nofill;                  /* NC_NOFILL: new variables are not pre-filled */
    int nvars_on_disk;           /* variables that already have data in the file */
    int64_t *old_begin;          /* their offsets before the header grew */
    int version;                 /* 1, 2, 5 */
@@ -377,6 +378,15 @@ static int transfer (nc3_file *f, int varid, void *mem, mem_t mt, int writing)
                      u = __builtin_bswap64 (u);
                      memcpy (&o[e], &u, 8);
                   }
+               } else if (v->type == NC3_FLOAT) {   /* fast path: POP history fields are float32 */
+                  for (size_t e = 0; e < m; e++) {
+                     uint32_t u;
+                     float x;
+                     memcpy (&u, buf + 4 * e, 4);
+                     u = __builtin_bswap32 (u);
+                     memcpy (&x, &u, 4);
+                     o[e] = (double) x;
+                  }
                } else
                   for (size_t e = 0; e < m; e++) o[e] = decode_double (buf + (size_t) esz * e, v->type);
             } else {
@@ -397,10 +407,24 @@ static int transfer (nc3_file *f, int varid, void *mem, mem_t mt, int writing)
          } else {
             if (mt == AS_DOUBLE) {
                const double *in = (const double *) mem + done;
-               for (size_t e = 0; e < m; e++) range_err |= encode_double (buf + (size_t) esz * e, v->type, in[e]);
+               if (v->type == NC3_DOUBLE) {      /* fast path: nzval_row_wise, tracer fields */
+                  for (size_t e = 0; e < m; e++) {
+                     uint64_t u;
+                     memcpy (&u, &in[e], 8);
+                     u = __builtin_bswap64 (u);
+                     memcpy (buf + 8 * e, &u, 8);
+                  }
+               } else
+                  for (size_t e = 0; e < m; e++) range_err |= encode_double (buf + (size_t) esz * e, v->type, in[e]);
             } else {
                const int *in = (const int *) mem + done;
-               for (size_t e = 0; e < m; e++) range_err |= encode_double (buf + (size_t) esz * e, v->type, (double) in[e]);
+               if (v->type == NC3_INT) {         /* fast path: colind, rowptr, index maps */
+                  for (size_t e = 0; e < m; e++) {
+                     uint32_t u = __builtin_bswap32 ((uint32_t) in[e]);
+                     memcpy (buf + 4 * e, &u, 4);
+                  }
+               } else
+                  for (size_t e = 0; e < m; e++) range_err |= encode_double (buf + (size_t) esz * e, v->type, (double) in[e]);
             }
             if (fwrite (buf, (size_t) esz, m, f->fp) != m) { free (buf); return NC3_EIO; }
          }
@@ -692,6 +716,22 @@ static void default_fill (int type, unsigned char *p)
    }
 }
 
+int nc3_set_fill (nc3_file *f, int fill)
+{
+   f->nofill = !fill;
+   return NC3_NOERR;
+}
+
+/* NC_NOFILL: reserve the variable's bytes without writing them (a hole the caller fills right away) */
+static int skip_var (FILE *fp, const var_t *v)
+{
+   uint64_t nbytes = var_bytes (v);
+   static const unsigned char zero[1] = { 0 };
+   if (nbytes == 0) return NC3_NOERR;
+   if (fseeko (fp, (off_t) (nbytes - 1), SEEK_CUR)) return NC3_EIO;
+   return fwrite (zero, 1, 1, fp) == 1 ? NC3_NOERR : NC3_EIO;
+}
+
 static int fill_var (FILE *fp, const var_t *v)
 {
    int esz = type_size[v->type];
@@ -774,7 +814,7 @@ int nc3_enddef (nc3_file *f)
       const var_t *v = &f->vars[i];
       if (v->is_record) continue;
       if (i < f->nvars_on_disk && f->old_begin) status = copy_bytes (f->fp, f->old_begin[i], out, var_bytes (v));
-      else status = fill_var (out, v);
+      else status = f->nofill ? skip_var (out, v) : fill_var (out, v);
    }
    if (!status && old_rec_begin >= 0 && f->numrecs) {
       (void) rec_begin;

@@ -67,6 +67,8 @@ int nc3_get_att_double (nc3_file *f, int varid, const char *attname, double *val
  * values (libnetcdf's NC_FILL default).  New record variables are not supported. */
 int nc3_create (const char *path, int version /* 1, 2 or 5 */, nc3_file **out);
 int nc3_redef (nc3_file *f);
+/* fill != 0 (default): pre-fill new variables at nc3_enddef (NC_FILL); 0: leave them unwritten (NC_NOFILL) */
+int nc3_set_fill (nc3_file *f, int fill);
 int nc3_enddef (nc3_file *f);
 int nc3_def_dim (nc3_file *f, const char *name, size_t len, int *dimid);
 int nc3_inq_dimid (nc3_file *f, const char *name, int *dimid);

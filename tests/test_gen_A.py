@@ -432,3 +432,27 @@ def test_pop_style_history_file_with_time_record(tmp_path):
     got = nc3.NcFile(str(tmp_path / "m.nc"))
     assert np.array_equal(got.get("colind"), want["colind"]) and np.array_equal(got.get("rowptr"), want["rowptr"])
     assert got.get("nzval_row_wise").tobytes() == want["nzval"].tobytes()
+
+
+def test_codec_nofill_reserves_without_writing(tmp_path):
+    """nc3_set_fill(f, 0) (NC_NOFILL): a new variable's bytes are reserved, not written -- what put_sparse_matrix
+    uses for the GB-sized arrays it overwrites immediately."""
+    import ctypes as C
+    from nk_ocn_tracer_jacobian_precond_amd import solver
+    L = C.CDLL(solver.HOST_LIB_PATH)
+    path = str(tmp_path / "n.nc")
+    fh = C.c_void_p()
+    assert L.nc3_create(path.encode(), 2, C.byref(fh)) == 0
+    assert L.nc3_set_fill(fh, 0) == 0
+    d, v = C.c_int(), C.c_int()
+    assert L.nc3_def_dim(fh, b"n", C.c_size_t(1000), C.byref(d)) == 0
+    assert L.nc3_def_var(fh, b"a", 6, 1, (C.c_int * 1)(d.value), C.byref(v)) == 0
+    assert L.nc3_def_var(fh, b"b", 4, 1, (C.c_int * 1)(d.value), None) == 0
+    assert L.nc3_close(fh) == 0
+    g = nc3.NcFile(path)
+    assert os.path.getsize(path) == g.vars["b"].begin + 4000
+    a = np.linspace(0.0, 1.0, 1000)
+    assert L.nc3_open(path.encode(), 1, C.byref(fh)) == 0
+    assert L.nc3_put_var_double(fh, 0, a.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    assert L.nc3_close(fh) == 0
+    assert np.array_equal(nc3.NcFile(path).get("a"), a)
