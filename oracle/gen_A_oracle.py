@@ -425,7 +425,9 @@ class _Gen:
 
     # ---- clean-up -----------------------------------------------------------------------
     def finish(self):
-        C, V = np.concatenate(self.C, 0), np.concatenate(self.V, 0)
+        width = max(c.shape[1] for c in self.C)        # tracers may carry different runs: pad with absent slots
+        C = np.concatenate([np.pad(c, ((0, 0), (0, width - c.shape[1])), constant_values=-1) for c in self.C], 0)
+        V = np.concatenate([np.pad(v, ((0, 0), (0, width - v.shape[1]))) for v in self.V], 0)
         ncol = C.shape[1]
         dup_cnt = 0
         for a in range(ncol):

@@ -456,3 +456,23 @@ def test_codec_nofill_reserves_without_writing(tmp_path):
     assert L.nc3_put_var_double(fh, 0, a.ctypes.data_as(C.POINTER(C.c_double))) == 0
     assert L.nc3_close(fh) == 0
     assert np.array_equal(nc3.NcFile(path).get("a"), a)
+
+
+# ---------------------------------------------------------------- committed fixtures (tests/golden/make_gen_A_golden.py)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("case", ["shipped_job", "cent_hor_file", "pair_po4_dop"])
+def test_committed_fixture(tmp_path, case):
+    """bin/gen_A on the committed circulation / source files against the matrices the restatement produced when
+    the fixtures were made (generic sink + const sink in one coupled pair: tracers with different row layouts)."""
+    r = subprocess.run([os.path.join(BIN, "gen_A"), "-o", f"gen_A_{case}.opt", str(tmp_path / "m.nc")], cwd=GOLDEN,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = np.load(os.path.join(GOLDEN, f"gen_A_{case}_expected.npz"))
+    got = nc3.NcFile(str(tmp_path / "m.nc"))
+    for key, var in (("rowptr", "rowptr"), ("colind", "colind"), ("KMT", "KMT"), ("int3_to_tracer_state_ind", "int3_to_tracer_state_ind"),
+                     ("ind_i", "tracer_state_ind_to_i"), ("ind_j", "tracer_state_ind_to_j"), ("ind_k", "tracer_state_ind_to_k")):
+        np.testing.assert_array_equal(got.get(var), want[key])
+    assert got.get("nzval_row_wise").tobytes() == want["nzval"].tobytes()

@@ -431,3 +431,24 @@ def test_unattainable_tolerance_stops_early(golden_by_name):
     s2 = solver.NkpSolver(g.rowptr, g.colind, g.val, g.blk_start, coupled_tracer_cnt=g.cnt, rtol=1e-10)
     x2, info2 = s2.solve(b)
     assert info2["status"] == 0 and (info2["relres"] <= 1e-10 or info2["berr"] <= 1e-12)
+
+
+def test_bench_size_properties():
+    """BASELINE.json configs[2], the bench workload (1 degree x 60 levels, n = 4.2 M, nnz = 73 M): the pipelined SpMV is
+    bit-identical to the oracle's at full size, the solve meets 1e-10 on a residual the oracle recomputes, and the
+    multilevel cycle is linear."""
+    p = synth.generate(imt=320, jmt=384, km=60, adv="upwind3", hmix="isop", seed=0)
+    blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(p.flat_len)
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj) as s:
+        assert np.array_equal(s.spmv(x), ora.spmv(p.rowptr, p.colind, p.nzval, x))
+        r1, r2 = rng.standard_normal(p.flat_len), rng.standard_normal(p.flat_len)
+        z1, z2, z3 = s.precond_apply(r1), s.precond_apply(r2), s.precond_apply(3.0 * r1 - r2)
+        assert np.linalg.norm(z3 - (3.0 * z1 - z2)) / np.linalg.norm(z3) <= 1e-9
+        b = rng.standard_normal(p.flat_len)
+        xs, info = s.solve(b)
+    assert info["status"] == 0 and info["iters"] < 1500
+    res = b - ora.spmv(p.rowptr, p.colind, p.nzval, xs)
+    assert np.linalg.norm(res) / np.linalg.norm(b) <= 1e-10
