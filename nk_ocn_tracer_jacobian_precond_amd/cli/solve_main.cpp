@@ -20,6 +20,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "../../include/nkp.h"
@@ -284,11 +286,16 @@ int main (int argc, char *argv[])
          }
       } else {
          int ok = 0;
+         const time_t launched = time (NULL);
          for (int tries = 0; tries < 1200 && !ok; tries++) {       // up to two minutes
-            FILE *f = fopen (idfile, "rb");
-            if (f) {
-               ok = fread (id, 1, sizeof id, f) == sizeof id;
-               fclose (f);
+            struct stat sb;
+            // a file left behind by an earlier job is not this job's id: only accept one written around our launch
+            if (stat (idfile, &sb) == 0 && sb.st_mtime + 60 >= launched) {
+               FILE *f = fopen (idfile, "rb");
+               if (f) {
+                  ok = fread (id, 1, sizeof id, f) == sizeof id;
+                  fclose (f);
+               }
             }
             if (!ok) usleep (100000);
          }
