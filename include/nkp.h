@@ -188,6 +188,14 @@ int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global,
                      const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt,
                      const nkp_comm_ops *comm);
 
+/* Multi-RHS concurrency: the reference solves its right-hand sides one after the other
+ * against one factorisation (RHS loop, src/solve_ABglobal.c:370-409).  nkp_clone gives a second set of work
+ * vectors and a second stream on the SAME device-resident matrix, factors and hierarchy (nothing is copied), so
+ * that several right-hand sides can be in flight at once: one clone per host thread, each calling nkp_solve /
+ * nkp_solve_device on its own handle.  Results are bit-identical to solving on the original.  Destroy clones
+ * (nkp_destroy) before the solver they were cloned from.  Single-GPU solvers only. */
+int nkp_clone (nkp_solver *src, nkp_solver **out);
+
 /* hipSetDevice for host programs that do not link HIP themselves (call before nkp_comm_rccl_init). */
 int nkp_set_device (int device);
 

@@ -20,7 +20,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <sys/stat.h>
+#include <thread>
+#include <vector>
 #include <time.h>
 #include <unistd.h>
 
@@ -350,54 +353,127 @@ int main (int argc, char *argv[])
       exit (EXIT_FAILURE);
    }
 
-   // each group of coupled_tracer_cnt consecutive names is one right-hand side
-   // (reference src/solve_ABglobal.c:370-409)
-   const char *varsep = ",";
-   for (char *var = strtok (vars, varsep); var; var = strtok (NULL, varsep)) {
-      for (int t = 0; t < coupled_tracer_cnt; t++) {
-         if (t > 0 && (var = strtok (NULL, varsep)) == NULL) {
-            fprintf (stderr, "(%d) error extracting tracer_ind=%d, ran out of var names\n", iam, t);
-            exit (EXIT_FAILURE);
+   // NKP_RHS_CONCURRENCY=K (single-GPU flavour): up to K right-hand sides in flight at once, each on its own clone
+   // of the solver (nkp_clone: own work vectors and stream, shared matrix and hierarchy) driven by its own host
+   // thread.  Groups are still written back in the order given, up to the first failure, so the files end up
+   // exactly as the sequential loop leaves them.
+   int concurrency = 1;
+   {
+      const char *e = getenv ("NKP_RHS_CONCURRENCY");
+      int v;
+      if (e && !parse_to_int ((char *) e, &v) && v > 1 && !use_comm) concurrency = v;
+   }
+   if (concurrency > 1) {
+      std::vector<std::vector<char *>> groups;
+      const char *sep = ",";
+      for (char *var = strtok (vars, sep); var; var = strtok (NULL, sep)) {
+         std::vector<char *> g;
+         for (int t = 0; t < coupled_tracer_cnt; t++) {
+            if (t > 0 && (var = strtok (NULL, sep)) == NULL) {
+               fprintf (stderr, "(%d) error extracting tracer_ind=%d, ran out of var names\n", iam, t);
+               exit (EXIT_FAILURE);
+            }
+            if (dbg_lvl)
+               printf ("(%d) processing variable %s\n", iam, var);
+            g.push_back (var);
          }
-         if (dbg_lvl)
-            printf ("(%d) processing variable %s\n", iam, var);
-         if ((vars_per_solve[t] = strdup (var)) == NULL) {
-            fprintf (stderr, "(%d) malloc failed in %s for vars_per_solve[%d]\n", iam, argv[0], t);
-            exit (EXIT_FAILURE);
-         }
+         groups.push_back (g);
       }
-      if (get_B_global (vars_per_solve, B))
-         exit (EXIT_FAILURE);
-
-      double berr = 0.0, relres = 0.0;
-      int iters = 0;
-      printf ("(%d) calling nkp_solve\n", iam);
+      const size_t ng = groups.size ();
+      std::vector<std::vector<double>> Bs (ng);
+      for (size_t g = 0; g < ng; g++) {
+         Bs[g].resize ((size_t) (flat_len ? flat_len : 1));
+         if (get_B_global (groups[g].data (), Bs[g].data ()))
+            exit (EXIT_FAILURE);
+      }
+      std::vector<nkp_solver *> handles (1, solver);
+      while (handles.size () < (size_t) concurrency && handles.size () < ng) {
+         nkp_solver *c = NULL;
+         if (nkp_clone (solver, &c)) {            // out of device memory: run with what there is
+            if (dbg_lvl)
+               printf ("(%d) nkp_clone: %s; continuing with %zu right-hand sides in flight\n", iam, nkp_last_error (), handles.size ());
+            break;
+         }
+         handles.push_back (c);
+      }
+      struct result { int info = 0, iters = 0; double berr = 0.0, relres = 0.0; std::string err; };
+      std::vector<result> res (ng);
+      printf ("(%d) calling nkp_solve for %zu right-hand sides, %zu in flight\n", iam, ng, handles.size ());
       fflush (stdout);
-      // every rank flattened the whole B; it solves for its own slice (ldb = m_loc, src/solve_ABdist.c:571)
-      info = nkp_solve (solver, B + fst_row, 1, m_loc, &berr, &iters, &relres);
-      if (dbg_lvl)
-         printf ("(%d) nkp_solve info = %d, iterations = %d, relres = %.3e, berr = %.3e\n", iam, info, iters, relres, berr);
-      if (info) {
-         fprintf (stderr, "(%d) nkp_solve failed (info = %d): %s\n(%d) %s left untouched in %s\n", iam, info, nkp_last_error (), iam,
-                  vars_per_solve[0], inout_fname);
-         exit (EXIT_FAILURE);
-      }
-      if (use_comm) {
-         // slices back to rank 0 (reference put_B_dist, src/solve_ABdist.c:377-406)
-         double *X = (iam == 0) ? (double *) malloc ((size_t) (flat_len ? flat_len : 1) * sizeof (double)) : NULL;
-         if (nkp_gather_root (solver, B + fst_row, X)) {
-            fprintf (stderr, "(%d) %s\n", iam, nkp_last_error ());
+      std::vector<std::thread> workers;
+      for (size_t w = 0; w < handles.size (); w++)
+         workers.emplace_back ([&, w] () {
+            for (size_t g = w; g < ng; g += handles.size ()) {
+               result &r = res[g];
+               r.info = nkp_solve (handles[w], Bs[g].data (), 1, flat_len, &r.berr, &r.iters, &r.relres);
+               if (r.info) r.err = nkp_last_error ();       // thread-local: capture it on the thread that failed
+            }
+         });
+      for (std::thread &t : workers) t.join ();
+      for (size_t w = 1; w < handles.size (); w++) nkp_destroy (handles[w]);
+      for (size_t g = 0; g < ng; g++) {
+         const result &r = res[g];
+         if (dbg_lvl)
+            printf ("(%d) nkp_solve info = %d, iterations = %d, relres = %.3e, berr = %.3e\n", iam, r.info, r.iters, r.relres, r.berr);
+         if (r.info) {
+            fprintf (stderr, "(%d) nkp_solve failed (info = %d): %s\n(%d) %s left untouched in %s\n", iam, r.info, r.err.c_str (), iam,
+                     groups[g][0], inout_fname);
             exit (EXIT_FAILURE);
          }
-         if (iam == 0) {
-            memcpy (B, X, (size_t) flat_len * sizeof (double));
-            free (X);
-         }
+         if (put_B_global (groups[g].data (), Bs[g].data ()))
+            exit (EXIT_FAILURE);
       }
-      if (iam == 0 && put_B_global (vars_per_solve, B))
-         exit (EXIT_FAILURE);
-      for (int t = 0; t < coupled_tracer_cnt; t++)
-         free (vars_per_solve[t]);
+   } else {
+   // each group of coupled_tracer_cnt consecutive names is one right-hand side
+      // (reference src/solve_ABglobal.c:370-409)
+      const char *varsep = ",";
+      for (char *var = strtok (vars, varsep); var; var = strtok (NULL, varsep)) {
+         for (int t = 0; t < coupled_tracer_cnt; t++) {
+            if (t > 0 && (var = strtok (NULL, varsep)) == NULL) {
+               fprintf (stderr, "(%d) error extracting tracer_ind=%d, ran out of var names\n", iam, t);
+               exit (EXIT_FAILURE);
+            }
+            if (dbg_lvl)
+               printf ("(%d) processing variable %s\n", iam, var);
+            if ((vars_per_solve[t] = strdup (var)) == NULL) {
+               fprintf (stderr, "(%d) malloc failed in %s for vars_per_solve[%d]\n", iam, argv[0], t);
+               exit (EXIT_FAILURE);
+            }
+         }
+         if (get_B_global (vars_per_solve, B))
+            exit (EXIT_FAILURE);
+
+         double berr = 0.0, relres = 0.0;
+         int iters = 0;
+         printf ("(%d) calling nkp_solve\n", iam);
+         fflush (stdout);
+         // every rank flattened the whole B; it solves for its own slice (ldb = m_loc, src/solve_ABdist.c:571)
+         info = nkp_solve (solver, B + fst_row, 1, m_loc, &berr, &iters, &relres);
+         if (dbg_lvl)
+            printf ("(%d) nkp_solve info = %d, iterations = %d, relres = %.3e, berr = %.3e\n", iam, info, iters, relres, berr);
+         if (info) {
+            fprintf (stderr, "(%d) nkp_solve failed (info = %d): %s\n(%d) %s left untouched in %s\n", iam, info, nkp_last_error (), iam,
+                     vars_per_solve[0], inout_fname);
+            exit (EXIT_FAILURE);
+         }
+         if (use_comm) {
+            // slices back to rank 0 (reference put_B_dist, src/solve_ABdist.c:377-406)
+            double *X = (iam == 0) ? (double *) malloc ((size_t) (flat_len ? flat_len : 1) * sizeof (double)) : NULL;
+            if (nkp_gather_root (solver, B + fst_row, X)) {
+               fprintf (stderr, "(%d) %s\n", iam, nkp_last_error ());
+               exit (EXIT_FAILURE);
+            }
+            if (iam == 0) {
+               memcpy (B, X, (size_t) flat_len * sizeof (double));
+               free (X);
+            }
+         }
+         if (iam == 0 && put_B_global (vars_per_solve, B))
+            exit (EXIT_FAILURE);
+         for (int t = 0; t < coupled_tracer_cnt; t++)
+            free (vars_per_solve[t]);
+      }
+
    }
 
    nkp_destroy (solver);

@@ -77,6 +77,7 @@ struct nkp_solver {
    nkp_options opt;
    int device = 0;
    bool stagnated = false;      // last solve stopped by the attainable-accuracy guard
+   bool borrowed = false;       // nkp_clone: matrix, factors and hierarchy belong to the solver this one was cloned from
    hipStream_t stream = nullptr;
    bool own_stream = false;
    CsrDev A;
@@ -124,6 +125,20 @@ static int dev_alloc (nkp_solver *s, T **p, size_t count)
 static void solver_free (nkp_solver *s)
 {
    if (!s) return;
+   if (s->borrowed) {           // a clone owns its work vectors, its level vectors and its stream, nothing else
+      void *own[] = { s->V, s->vcur, s->Z, s->w, s->r, s->x, s->b, s->t1, s->t2, s->partial, s->dscal, s->dint };
+      for (void *p : own)
+         if (p) (void) hipFree (p);
+      for (MlLevel &L : s->ml.lev) {
+         void *lv[] = { L.x, L.b, L.r };
+         for (void *p : lv)
+            if (p) (void) hipFree (p);
+      }
+      if (s->hpin) (void) hipHostFree (s->hpin);
+      if (s->own_stream && s->stream) (void) hipStreamDestroy (s->stream);
+      delete s;
+      return;
+   }
    void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.grp_row0, s->B.col_slot, s->B.fac_t, s->V, s->vcur, s->Z, s->w, s->r,
                     s->x, s->b, s->t1, s->t2, s->partial, s->dscal, s->dint };
    for (void *p : ptrs)
@@ -684,6 +699,60 @@ extern "C" int nkp_solve_device (nkp_solver *s, const void *d_b, void *d_x, int 
    HIPCHK (hipMemcpyAsync (d_x, s->x, bytes, hipMemcpyDeviceToDevice, s->stream));
    HIPCHK (hipStreamSynchronize (s->stream));
    return status;
+}
+
+// A second set of work vectors (Krylov basis, level vectors, scalars) and a second stream on the SAME device-resident
+// matrix, factors and hierarchy: several right-hand sides can then be solved concurrently from different host threads,
+// one clone per thread.  Single-GPU solvers only.
+extern "C" int nkp_clone (nkp_solver *src, nkp_solver **out)
+{
+   if (!src || !out) return fail (NKP_EINVAL, "nkp_clone: NULL argument");
+   *out = nullptr;
+   if (src->dist.on) return fail (NKP_EINVAL, "nkp_clone: not available for the row-distributed flavour");
+   if (src->borrowed) return fail (NKP_EINVAL, "nkp_clone: clone the original solver, not a clone");
+   HIPCHK (hipSetDevice (src->device));
+   nkp_solver *s = new (std::nothrow) nkp_solver (*src);
+   if (!s) return fail (NKP_ENOMEM, "nkp_clone: out of host memory");
+   s->borrowed = true;
+   s->stagnated = false;
+   s->stream = nullptr;
+   s->own_stream = false;
+   s->device_bytes = 0;
+   s->V = s->vcur = s->Z = s->w = s->r = s->x = s->b = s->t1 = s->t2 = s->partial = s->dscal = s->hpin = nullptr;
+   s->dint = nullptr;
+   for (MlLevel &L : s->ml.lev) L.x = L.b = L.r = nullptr;
+   int rc = NKP_OK;
+#define TRY(x) do { rc = (x); if (rc != NKP_OK) { solver_free (s); return rc; } } while (0)
+#define TRYHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = fail (NKP_EDEVICE, "%s failed: %s", #call, hipGetErrorString (e_)); solver_free (s); return rc; } } while (0)
+   TRYHIP (hipStreamCreateWithFlags (&s->stream, hipStreamNonBlocking));
+   s->own_stream = true;
+   const int m = s->m;
+   TRY (dev_alloc (s, &s->V, (size_t) s->ld * (size_t) (m + 1)));
+   TRY (dev_alloc (s, &s->vcur, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->Z, (size_t) s->ld * (size_t) m));
+   TRY (dev_alloc (s, &s->w, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->r, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->x, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->b, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->t1, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->t2, (size_t) s->ld));
+   TRY (dev_alloc (s, &s->partial, (size_t) ((m + 1 + NKP_DOT_CHUNK) / NKP_DOT_CHUNK + 1) * NKP_RED_BLOCKS * (NKP_DOT_CHUNK + 1)));
+   TRY (dev_alloc (s, &s->dscal, (size_t) (3 * (m + 2) + 16 + 8)));
+   TRY (dev_alloc (s, &s->dint, 8));
+   TRYHIP (hipHostMalloc ((void **) &s->hpin, (size_t) (m + 16) * sizeof (double), hipHostMallocDefault));
+   TRYHIP (hipMemset (s->dscal, 0, (size_t) (3 * (m + 2) + 16 + 8) * sizeof (double)));
+   for (MlLevel &L : s->ml.lev) {
+      TRY (dev_alloc (s, &L.x, (size_t) L.n));
+      TRY (dev_alloc (s, &L.b, (size_t) L.n));
+      TRY (dev_alloc (s, &L.r, (size_t) L.n));
+      TRYHIP (hipMemset (L.x, 0, (size_t) (L.n ? L.n : 1) * sizeof (double)));
+      TRYHIP (hipMemset (L.b, 0, (size_t) (L.n ? L.n : 1) * sizeof (double)));
+      TRYHIP (hipMemset (L.r, 0, (size_t) (L.n ? L.n : 1) * sizeof (double)));
+   }
+#undef TRY
+#undef TRYHIP
+   *out = s;
+   return NKP_OK;
 }
 
 extern "C" int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t ldb, double *berr, int *iters, double *relres)

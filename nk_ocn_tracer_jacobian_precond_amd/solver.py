@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "nkp_spmv", "nkp_spmv_device", "nkp_precond_apply", "nkp_multi_dot", "nkp_time_kernel",
     "nkp_get_int", "nkp_set_stream", "nkp_destroy", "nkp_last_error", "nkp_comm_unique_id",
     "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host", "nkp_set_device",
-    "nkp_gather_root",
+    "nkp_gather_root", "nkp_clone",
 ]
 
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
@@ -96,6 +96,7 @@ def load_library(path=None):
                                     i32p, i32p, f64p, i32p, C.c_int64, C.c_int, C.POINTER(NkpCommOps)]
     lib.nkp_set_device.argtypes = [C.c_int]
     lib.nkp_gather_root.argtypes = [vp, f64p, f64p]
+    lib.nkp_clone.argtypes = [vp, C.POINTER(vp)]
     lib.nkp_dist_plan_host.argtypes = [C.c_int64, C.c_int64, i32p, i32p, C.c_int, C.c_int, C.POINTER(C.c_int64), i32p, i32p,
                                        C.POINTER(C.c_int64), i32p]
     if path == HIP_LIB_PATH:
@@ -210,6 +211,15 @@ class NkpSolver:
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.nkp_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def clone(self):
+        """A second handle on the same device-resident matrix and hierarchy with its own work vectors and stream
+        (nkp_clone): solve another right-hand side concurrently from another thread.  Close it before this one."""
+        h = C.c_void_p()
+        self._check(self._lib.nkp_clone(self._h, C.byref(h)))
+        c = object.__new__(NkpSolver)
+        c._lib, c._h, c.n, c.nnz, c.options, c._parent = self._lib, h, self.n, self.nnz, self.options, self
+        return c
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
