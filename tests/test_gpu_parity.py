@@ -358,7 +358,7 @@ def test_multilevel_cycle_matches_independent_restatement(grid, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("job", ["shipped", "coupled_pair"])
+@pytest.mark.parametrize("job", ["shipped", "coupled_pair", "generic_sink", "vmix_matrix"])
 def test_gen_A_to_solve_pipeline(tmp_path, job):
     """The reference's whole chain (test/test_gen_A.csh -> test/test_solve_ABglobal.csh): circulation file
     -> bin/gen_A -> matrix file -> bin/solve_ABglobal on the GPU; the solution is checked against SuperLU
@@ -367,7 +367,7 @@ def test_gen_A_to_solve_pipeline(tmp_path, job):
     import scipy.sparse.linalg as spla
     from nk_ocn_tracer_jacobian_precond_amd import circ
 
-    F, fills = circ.make_circulation(24, 20, 12, seed=2)
+    F, fills = circ.make_circulation(24, 20, 12, seed=2, with_vmix_matrix=(job == "vmix_matrix"))
     cpath, mpath, tpath = str(tmp_path / "circ.nc"), str(tmp_path / "matrix.nc"), str(tmp_path / "tracers.nc")
     circ.write_circ_file(cpath, F, fills, nc_type="float32")
     opt = f"circ_fname {cpath}\nadv_type upwind3\nhmix_type isop_file\nvmix_type file\nsink_type const_shallow 365.0 10.0e2\n"
@@ -378,6 +378,15 @@ def test_gen_A_to_solve_pipeline(tmp_path, job):
         opt = (f"circ_fname {cpath}\ntracer_fname {tmp_path / 'src.nc'}\nadv_type cent\nhmix_type const\nvmix_type file\n"
                "coupled_tracer_cnt 2\ncoupled_tracer_type OCMIP_BGC_PO4_DOP\nsink_type const 0.5\ntracer_ind 1\nsink_type const_shallow 2.0 3.0e3\n")
         names = ["OCMIP_BGC_PO4", "OCMIP_BGC_DOP"]
+    elif job == "generic_sink":
+        # rows reach up to the three shallowest levels of their column: in-column entries far outside the band
+        T = circ.make_tracer_sources(F, seed=2)
+        circ.write_tracer_source_file(str(tmp_path / "src.nc"), F, T)
+        opt = (f"circ_fname {cpath}\ntracer_fname {tmp_path / 'src.nc'}\nadv_type upwind3\nhmix_type isop_file\nvmix_type file\n"
+               "sink_type generic_tracer ABIO_DIC14 3\npv PV\n")
+    elif job == "vmix_matrix":
+        # dense water-column blocks (whole-column implicit mixing operator)
+        opt = f"circ_fname {cpath}\nadv_type cent\nhmix_type const\nvmix_type matrix_file\nsink_type const 1.0\n"
     (tmp_path / "gen_A.opt").write_text(opt)
     r = subprocess.run([os.path.join(BIN, "gen_A"), "-o", str(tmp_path / "gen_A.opt"), mpath], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
