@@ -162,15 +162,22 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
 // Same products, same per-row summation order => bit-identical results.
 #define SPMV_SLOTS (SPMV_LDS_NNZ / SPMV_THREADS)
 
-template <int MODE, class VT>
+// CODED: the column stream is read as 2-byte codes (build_spmv_codes_host: row-in-block in the low byte, index into the
+// row block's dictionary of (column - row) offsets in the high byte) -- 10 instead of 12 bytes per entry for the f64
+// operator, 6 instead of 8 for the f32 level operators.  The next block's dictionary is fetched into the other half of
+// a double-buffered LDS table while the current block is consumed.  Blocks the coder gave up on (more than 256
+// distinct offsets, long rows) have an empty dictionary and fall back to colind.
+template <int MODE, class VT, bool CODED>
 __global__ __launch_bounds__ (SPMV_THREADS)
 void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk,
                            const int *__restrict__ rowptr, const int *__restrict__ colind,
                            const VT *__restrict__ val, const double *__restrict__ x,
-                           double *__restrict__ y, const double *__restrict__ b)
+                           double *__restrict__ y, const double *__restrict__ b,
+                           const unsigned short *__restrict__ codes, const int *__restrict__ dict, const int *__restrict__ dict_ptr)
 {
    __shared__ double prod[SPMV_LDS_NNZ];
    __shared__ double wsum[SPMV_THREADS / NKP_WAVE];
+   __shared__ int dict_s[CODED ? 2 : 1][CODED ? 256 : 1];
    const int tid = threadIdx.x;
    const int *rowblk = rowblk_all + rb0;
    // XCD-aware contiguous run of row blocks for this workgroup
@@ -185,16 +192,33 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
    int r0 = rowblk[lb], r1 = rowblk[lb + 1];
    int e0 = rowptr[r0], e1 = rowptr[r1];
    VT v[SPMV_SLOTS];
-   int c[SPMV_SLOTS];
+   int c[SPMV_SLOTS];           // column, or its code while the block waits to be consumed
    int seg0 = 0, seg1 = 0;
-#pragma unroll
-   for (int u = 0; u < SPMV_SLOTS; u++) {
-      const int e = e0 + tid + u * SPMV_THREADS;
-      const bool ok = e < e1 && e - e0 < SPMV_LDS_NNZ;
-      v[u] = ok ? val[e] : (VT) 0;
-      c[u] = ok ? colind[e] : 0;
-   }
-   if (r0 + tid < r1) { seg0 = rowptr[r0 + tid]; seg1 = rowptr[r0 + tid + 1]; }
+   int nd = 0;                  // dictionary length of the current block (0: columns are plain)
+   int cur = 0;                 // which half of dict_s holds it
+
+   // synchronous load of block lb into the registers (first block, and after a long-row block)
+#define SPMV_LOAD_CURRENT()                                                                        \
+   do {                                                                                            \
+      int d0_ = 0;                                                                                 \
+      nd = 0;                                                                                      \
+      if (CODED) { d0_ = dict_ptr[rb0 + lb]; nd = dict_ptr[rb0 + lb + 1] - d0_; }                  \
+      _Pragma ("unroll")                                                                           \
+      for (int u = 0; u < SPMV_SLOTS; u++) {                                                       \
+         const int e = e0 + tid + u * SPMV_THREADS;                                                \
+         const bool ok = e < e1 && e - e0 < SPMV_LDS_NNZ;                                          \
+         v[u] = ok ? val[e] : (VT) 0;                                                              \
+         c[u] = ok ? ((CODED && nd > 0) ? (int) codes[e] : colind[e]) : 0;                         \
+      }                                                                                            \
+      seg0 = seg1 = 0;                                                                             \
+      if (r0 + tid < r1) { seg0 = rowptr[r0 + tid]; seg1 = rowptr[r0 + tid + 1]; }                \
+      if (CODED) {                                                                                 \
+         if (tid < nd) dict_s[cur][tid] = dict[d0_ + tid];                                         \
+         __syncthreads ();                                                                         \
+      }                                                                                            \
+   } while (0)
+
+   SPMV_LOAD_CURRENT ();
 
    for (;;) {
       const int cnt = e1 - e0;
@@ -222,21 +246,29 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
          }
          __syncthreads ();
       } else {
-         // gathers of this block, then the NEXT block's stream requests, then consume the gathers
+         // decode, gather this block, request the NEXT block's streams (and dictionary), then consume the gathers
+         if (CODED && nd > 0) {
+#pragma unroll
+            for (int u = 0; u < SPMV_SLOTS; u++) c[u] = r0 + (c[u] & 255) + dict_s[cur][(c[u] >> 8) & 255];
+         }
          double xg[SPMV_SLOTS];
 #pragma unroll
          for (int u = 0; u < SPMV_SLOTS; u++) xg[u] = (tid + u * SPMV_THREADS < cnt) ? x[c[u]] : 0.0;
          VT nv[SPMV_SLOTS];
          int nc[SPMV_SLOTS];
          int nseg0 = 0, nseg1 = 0;
+         int nnd = 0, nd0 = 0;
+         if (CODED && have_next) { nd0 = dict_ptr[rb0 + lb + 1]; nnd = dict_ptr[rb0 + lb + 2] - nd0; }
 #pragma unroll
          for (int u = 0; u < SPMV_SLOTS; u++) {
             const int e = e1 + tid + u * SPMV_THREADS;
             const bool ok = have_next && e < ne1 && e - e1 < SPMV_LDS_NNZ;
             nv[u] = ok ? val[e] : (VT) 0;
-            nc[u] = ok ? colind[e] : 0;
+            nc[u] = ok ? ((CODED && nnd > 0) ? (int) codes[e] : colind[e]) : 0;
          }
          if (have_next && r1 + tid < nr1) { nseg0 = rowptr[r1 + tid]; nseg1 = rowptr[r1 + tid + 1]; }
+         // the other half of dict_s was last read while block lb - 1 was decoded, two barriers ago
+         if (CODED && tid < nnd) dict_s[cur ^ 1][tid] = dict[nd0 + tid];
 #pragma unroll
          for (int u = 0; u < SPMV_SLOTS; u++) {
             const int k = tid + u * SPMV_THREADS;
@@ -261,6 +293,8 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
          for (int u = 0; u < SPMV_SLOTS; u++) { v[u] = nv[u]; c[u] = nc[u]; }
          seg0 = nseg0;
          seg1 = nseg1;
+         nd = nnd;
+         cur ^= 1;
          if (!have_next) break;
          lb++;
          r0 = r1; r1 = nr1; e0 = e1; e1 = ne1;
@@ -270,16 +304,9 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
       if (!have_next) break;
       lb++;
       r0 = r1; r1 = nr1; e0 = e1; e1 = ne1;
-#pragma unroll
-      for (int u = 0; u < SPMV_SLOTS; u++) {
-         const int e = e0 + tid + u * SPMV_THREADS;
-         const bool ok = e < e1 && e - e0 < SPMV_LDS_NNZ;
-         v[u] = ok ? val[e] : (VT) 0;
-         c[u] = ok ? colind[e] : 0;
-      }
-      seg0 = seg1 = 0;
-      if (r0 + tid < r1) { seg0 = rowptr[r0 + tid]; seg1 = rowptr[r0 + tid + 1]; }
+      SPMV_LOAD_CURRENT ();
    }
+#undef SPMV_LOAD_CURRENT
 }
 
 void build_rowblocks_host (int64_t n, const int *rowptr, int **rowblk_out, int *nrowblk_out)
@@ -337,8 +364,11 @@ static void launch_range (const CsrDev &A, int rb0, int cnt, const double *x, do
       if (wgs > 256 * per_cu) wgs = 256 * per_cu;
       wgs &= ~7;
       if (wgs < 8) wgs = 8;
-      if (A.valf) hipLaunchKernelGGL ((csr_spmv_pipe_kernel<MODE, float>), dim3 (wgs), dim3 (SPMV_THREADS), 0, st, A.rowblk, rb0, cnt, A.rowptr, A.colind, A.valf, x, y, b);
-      else hipLaunchKernelGGL ((csr_spmv_pipe_kernel<MODE, double>), dim3 (wgs), dim3 (SPMV_THREADS), 0, st, A.rowblk, rb0, cnt, A.rowptr, A.colind, A.val, x, y, b);
+#define SPMV_PIPE(VT_, CODED_, VAL_) hipLaunchKernelGGL ((csr_spmv_pipe_kernel<MODE, VT_, CODED_>), dim3 (wgs), dim3 (SPMV_THREADS), 0, st, \
+                                                         A.rowblk, rb0, cnt, A.rowptr, A.colind, VAL_, x, y, b, A.codes, A.dict, A.dict_ptr)
+      if (A.valf) { if (A.codes) SPMV_PIPE (float, true, A.valf); else SPMV_PIPE (float, false, A.valf); }
+      else { if (A.codes) SPMV_PIPE (double, true, A.val); else SPMV_PIPE (double, false, A.val); }
+#undef SPMV_PIPE
       return;
    }
    if (A.valf) {
@@ -436,8 +466,10 @@ double build_spmv_codes_host (int64_t n, const int *rowptr, const int *colind, c
 
 int attach_spmv_codes (CsrDev &A, const int *h_rowptr, const int *h_colind, const int *h_rowblk, size_t *device_bytes)
 {
-   // off by default: measured at 1 degree the 2-byte codes do not shorten the kernel (it is latency-, not
-   // byte-bound: removing the whole value stream did not either), and building them costs ~2.7 s of setup
+   // off by default (NKP_SPMV_COMPRESS=1 turns it on): measured at 1 degree the 2-byte codes do not shorten the
+   // kernels -- pipelined f64 SpMV 0.236 ms coded against 0.203 ms plain on the same box, V-cycle 2.93 against 2.69 ms:
+   // the dictionary lookup sits in front of the x gather and lengthens the dependent chain by more than the 2 bytes
+   // per entry save -- and building them costs ~2.7 s of setup
    const char *e = getenv ("NKP_SPMV_COMPRESS");
    if (!e || atoi (e) == 0) return 0;
    if (A.nnz == 0 || A.nrowblk == 0) return 0;
