@@ -336,16 +336,17 @@ void launch_restrict_sum (const int *rptr, const int *ridx, const double *fine, 
 }
 
 __global__ __launch_bounds__ (B1_THREADS)
-void prolong_add_kernel (const int *__restrict__ cmap, const double *__restrict__ coarse, double *__restrict__ fine, int64_t nf)
+void prolong_add_kernel (const int *__restrict__ cmap, const double *__restrict__ coarse, double *__restrict__ fine, int64_t nf, double omega)
 {
    const int64_t stride = (int64_t) gridDim.x * B1_THREADS;
-   for (int64_t i = (int64_t) blockIdx.x * B1_THREADS + threadIdx.x; i < nf; i += stride) fine[i] += coarse[cmap[i]];
+   for (int64_t i = (int64_t) blockIdx.x * B1_THREADS + threadIdx.x; i < nf; i += stride) fine[i] += omega * coarse[cmap[i]];
 }
 
-void launch_prolong_add (const int *cmap, const double *coarse, double *fine, int64_t nf, hipStream_t st)
+// fine += omega * P coarse (omega = 1: the plain piecewise-constant prolongation; x * 1.0 is exact)
+void launch_prolong_add (const int *cmap, const double *coarse, double *fine, int64_t nf, double omega, hipStream_t st)
 {
    if (nf <= 0) return;
-   hipLaunchKernelGGL (prolong_add_kernel, dim3 (red_grid (nf) * 2), dim3 (B1_THREADS), 0, st, cmap, coarse, fine, nf);
+   hipLaunchKernelGGL (prolong_add_kernel, dim3 (red_grid (nf) * 2), dim3 (B1_THREADS), 0, st, cmap, coarse, fine, nf, omega);
 }
 
 __global__ __launch_bounds__ (B1_THREADS)

@@ -583,6 +583,7 @@ static void gs_sweep (MlLevel &V, bool reverse, hipStream_t st)
 
 static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
 {
+   if (H.omega == 0.0) { const char *e = getenv ("NKP_ML_OMEGA"); H.omega = (e && atof (e) > 0.0) ? atof (e) : 1.0; }
    MlLevel &V = H.lev[l];
    if (l == (int) H.lev.size () - 1) {
       launch_dense_matvec (H.coarse_inv, V.b, V.x, (int) V.n, st);
@@ -600,7 +601,7 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
    MlLevel &C = H.lev[l + 1];
    launch_restrict_sum (V.rptr, V.ridx, V.r, C.b, V.nc, st);
    ml_cycle (H, l + 1, st);
-   launch_prolong_add (V.cmap, C.x, V.x, V.n, st);
+   launch_prolong_add (V.cmap, C.x, V.x, V.n, H.omega, st);
    for (int s = 0; s < nu; s++) gs_sweep (V, true, st);
 }
 

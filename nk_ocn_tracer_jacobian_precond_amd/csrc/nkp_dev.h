@@ -115,7 +115,7 @@ void launch_fill (double *y, double v, int64_t n, hipStream_t st);
 // coarse[I] = sum_{q in [rptr[I], rptr[I+1])} fine[ridx[q]]   (restriction = P^T, fixed order)
 void launch_restrict_sum (const int *rptr, const int *ridx, const double *fine, double *coarse, int64_t nc, hipStream_t st);
 // fine[i] += coarse[cmap[i]]                                  (prolongation = P)
-void launch_prolong_add (const int *cmap, const double *coarse, double *fine, int64_t nf, hipStream_t st);
+void launch_prolong_add (const int *cmap, const double *coarse, double *fine, int64_t nf, double omega, hipStream_t st);
 // out[i] = in[perm[i]]
 void launch_gather (const int *perm, const double *in, double *out, int64_t n, hipStream_t st);
 // out[perm[i]] = in[i]

@@ -100,13 +100,21 @@ class TorchComm:
         self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
         self.device_native = dist.get_backend() == "nccl"
         self.errors = []
+        self._views = {}
         self._fns = (_solver._ALLREDUCE_FN(self._allreduce), _solver._ALLTOALLV_FN(self._alltoallv),
                      _solver._ALLTOALLV_I32_FN(self._alltoallv_i32_host), _solver._ALLGATHER_I64_FN(self._allgather_i64_host))
         self.ops = _solver.NkpCommOps(None, self.rank, self.nranks, *self._fns)
 
     # ---- helpers
     def _dev(self, ptr, n):
-        return self.torch.as_tensor(_DevArray(ptr, n, "<f8"), device="cuda")
+        # the library's device buffers live as long as the solver: wrap each (address, length) once
+        key = (int(ptr), int(n))
+        t = self._views.get(key)
+        if t is None:
+            t = self.torch.as_tensor(_DevArray(ptr, n, "<f8"), device="cuda")
+            if len(self._views) < 4096:
+                self._views[key] = t
+        return t
 
     def _exchange_host(self, send, scnt, recv, rcnt):
         """alltoallv of 1-D CPU tensors with isend/irecv (gloo has no all_to_all)."""
