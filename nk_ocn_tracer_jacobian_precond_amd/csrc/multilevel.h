@@ -25,6 +25,7 @@ struct MlHierarchy {
    int nu_coarse = 1;           // ... on levels >= coarse_from
    int coarse_from = 2;
    int f32 = 1;                 // store level operators / factors in f32 (arithmetic stays f64)
+   int gamma_from = 0, gamma_to = 0;   // levels [from, to) apply the coarse-grid correction twice (W-cycle there)
    double omega = 0.0;          // scaling of the coarse-grid correction (0 = not read yet; NKP_ML_OMEGA, default 1)
    size_t device_bytes = 0;
 };

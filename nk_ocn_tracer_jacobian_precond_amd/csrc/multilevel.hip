@@ -583,7 +583,12 @@ static void gs_sweep (MlLevel &V, bool reverse, hipStream_t st)
 
 static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
 {
-   if (H.omega == 0.0) { const char *e = getenv ("NKP_ML_OMEGA"); H.omega = (e && atof (e) > 0.0) ? atof (e) : 1.0; }
+   if (H.omega == 0.0) {
+      const char *e = getenv ("NKP_ML_OMEGA");
+      H.omega = (e && atof (e) > 0.0) ? atof (e) : 1.0;
+      if ((e = getenv ("NKP_ML_GAMMA_FROM"))) H.gamma_from = atoi (e);
+      if ((e = getenv ("NKP_ML_GAMMA_TO"))) H.gamma_to = atoi (e);
+   }
    MlLevel &V = H.lev[l];
    if (l == (int) H.lev.size () - 1) {
       launch_dense_matvec (H.coarse_inv, V.b, V.x, (int) V.n, st);
@@ -596,12 +601,16 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
    launch_colblock_apply_lanes (V.B, V.color_grp[1], V.color_grp[2], V.r, V.x, 1, st);
    const int nu = (l >= H.coarse_from) ? H.nu_coarse : H.nu;
    for (int s = 1; s < nu; s++) gs_sweep (V, false, st);
-   // coarse-grid correction
-   launch_csr_spmv (V.L, V.x, V.r, V.b, 1, st);
+   // coarse-grid correction; levels in [gamma_from, gamma_to) repeat it on the updated residual, which by the
+   // Galerkin property is the second coarse iteration of a W-cycle (NKP_ML_GAMMA_FROM / NKP_ML_GAMMA_TO, default off)
    MlLevel &C = H.lev[l + 1];
-   launch_restrict_sum (V.rptr, V.ridx, V.r, C.b, V.nc, st);
-   ml_cycle (H, l + 1, st);
-   launch_prolong_add (V.cmap, C.x, V.x, V.n, H.omega, st);
+   const int gamma = (l >= H.gamma_from && l < H.gamma_to) ? 2 : 1;
+   for (int g = 0; g < gamma; g++) {
+      launch_csr_spmv (V.L, V.x, V.r, V.b, 1, st);
+      launch_restrict_sum (V.rptr, V.ridx, V.r, C.b, V.nc, st);
+      ml_cycle (H, l + 1, st);
+      launch_prolong_add (V.cmap, C.x, V.x, V.n, H.omega, st);
+   }
    for (int s = 0; s < nu; s++) gs_sweep (V, true, st);
 }
 
