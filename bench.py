@@ -308,7 +308,7 @@ def main():
                   "relres_checked_with_torch": relres_check, "setup_s": t_setup, "generate_s": t_gen,
                   "levels": s.get_int("levels"), "device_MB": s.get_int("device_bytes") / 1e6,
                   "precond_apply_ms": pre_ms, "krylov_iteration_ms": it_ms},
-        "roofline": {"kernel": "csr_spmv_pipe_kernel<0, double>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "csr_spmv_pipe_kernel<0, double, false>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": spmv_bytes, "avg_launch_ms": spmv_ms,
                      # context only: the guide's measured float4-copy ceiling (MI355X_MICROARCH.md: 6.29 TB/s)
