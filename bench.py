@@ -301,12 +301,14 @@ def main():
         "config": {
             "workload": f"{a.grid} ({'1' if imt == 320 else '?'} degree x {km} level) {tracer_text} ocean Jacobian, "
                         f"adv={a.adv} hmix={a.hmix}, n={n_global}, nnz={nnz_global}; FGMRES({a.restart}) + multilevel water-column "
-                        f"preconditioner V({a.ml_smooth},{a.ml_smooth}), rtol={a.rtol:g}; one solve per step, rhs resident in HBM",
+                        f"preconditioner V({a.ml_smooth},{a.ml_smooth}) x {s.get_int('precond_steps')} per iteration (defect correction), rtol={a.rtol:g}; "
+                        f"one solve per step, rhs resident in HBM",
             "multi_gpu": mode,
         },
         "solve": {"iterations": iters, "relres": [i["relres"] for i in infos], "berr": [i["berr"] for i in infos],
                   "relres_checked_with_torch": relres_check, "setup_s": t_setup, "generate_s": t_gen,
-                  "levels": s.get_int("levels"), "device_MB": s.get_int("device_bytes") / 1e6,
+                  "levels": s.get_int("levels"), "precond_cycles_per_iteration": s.get_int("precond_steps"),
+                  "device_MB": s.get_int("device_bytes") / 1e6,
                   "precond_apply_ms": pre_ms, "krylov_iteration_ms": it_ms},
         "roofline": {"kernel": "csr_spmv_pipe_kernel<0, double, false>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -79,7 +79,9 @@ typedef struct nkp_options {
    int basis_f32;        /* 1: store the Krylov basis V in f32 for the Gram-Schmidt passes (the solution update uses
                             the f64 Z vectors, the true residual is recomputed in f64 at every restart).  Default 0:
                             with a single Gram-Schmidt pass the f32 basis can double the iteration count. */
-   int reserved[6];
+   int precond_steps;    /* preconditioner cycles per Krylov iteration, chained by defect correction against A:
+                            z = M r; z += M (r - A z); ...  0 = automatic (multilevel: 2, 3 from 6 M rows; else 1)      */
+   int reserved[5];
    /* multilevel, optional: grid position (i, j) of every water-column block, nblk entries each
     * (tracer_state_ind_to_i/_j at the block's first row, reference src/matrix.c:322-329).  With
     * them columns are aggregated 2 x 2 in (i, j) and coloured (i + j) % 2; without them

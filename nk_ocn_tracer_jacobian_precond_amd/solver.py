@@ -46,7 +46,7 @@ class NkpOptions(C.Structure):
         ("struct_size", C.c_int), ("precond", C.c_int), ("krylov", C.c_int), ("restart", C.c_int),
         ("max_iters", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("device", C.c_int),
         ("verbose", C.c_int), ("rank", C.c_int), ("reorth", C.c_int), ("ml_levels", C.c_int),
-        ("ml_smooth", C.c_int), ("basis_f32", C.c_int), ("reserved", C.c_int * 6),
+        ("ml_smooth", C.c_int), ("basis_f32", C.c_int), ("precond_steps", C.c_int), ("reserved", C.c_int * 5),
         ("col_i", C.POINTER(C.c_int32)), ("col_j", C.POINTER(C.c_int32)),
     ]
 
