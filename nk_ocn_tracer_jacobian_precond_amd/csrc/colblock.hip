@@ -507,10 +507,151 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    return (int) hipStreamSynchronize (st);
 }
 
+// Software-pipelined variant for the common shape (f32 factors, columns of at most 64 levels, 8 columns per wave,
+// half bandwidth <= 2).  SQ counters on the one-group-per-wave kernel above: a wave lives ~14 us, 46 % of it parked on
+// the staging loads, and LDS (14.5 KB per wave) caps a CU at 11 waves.  Here a persistent wave walks groups g,
+// g + gridDim.x, ...: it commits the prefetched registers of group i to LDS, requests group i+1 (index words, then
+// right-hand side, accumulate target and the factor block: 26 registers of loads in flight) and only then runs group
+// i's recurrence, so the HBM latency hides under arithmetic.  Same arithmetic in the same order => same bits.
+#define LANES_PIPE_BATCH 10
+template <int P>
+__global__ __launch_bounds__ (NKP_WAVE)
+void colblock_apply_lanes_pipe_kernel (const int *__restrict__ grp_nb, const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base,
+                                       int g_first, int g_end, const float *__restrict__ fac_t, const double *__restrict__ rhs,
+                                       double *__restrict__ z, int accumulate, int rhs_slots, const int *__restrict__ grp_row0,
+                                       const int *__restrict__ col_slot, int ngrp)
+{
+   extern __shared__ double lds[];
+   constexpr int gw = 8, MAXL = 64;
+   float *fl = reinterpret_cast<float *> (lds + rhs_slots);
+   const int lane = threadIdx.x;
+   int g = g_first + (int) blockIdx.x;
+   if (g >= g_end) return;
+
+   int n_nb, n_ml, n_R0, n_nrows, n_s, n_len;
+   double n_tz[8], n_tr[8];
+   double2 n_t[LANES_PIPE_BATCH];
+#define LANES_PREFETCH(GG)                                                                            \
+   do {                                                                                               \
+      n_nb = grp_nb[GG];                                                                              \
+      n_ml = grp_maxlen[GG];                                                                          \
+      n_R0 = grp_row0[GG];                                                                            \
+      n_nrows = grp_row0[ngrp + (GG)];                                                                \
+      n_s = n_len = 0;                                                                                \
+      if (lane < gw) { n_s = col_slot[(GG) * gw + lane]; n_len = col_slot[(ngrp + (GG)) * gw + lane]; } \
+      _Pragma ("unroll")                                                                              \
+      for (int u = 0; u < 8; u++) {                                                                   \
+         const int i = lane + u * NKP_WAVE;                                                           \
+         n_tz[u] = (accumulate && i < n_nrows) ? z[(int64_t) n_R0 + i] : 0.0;                         \
+         n_tr[u] = (i < n_nrows) ? rhs[(int64_t) n_R0 + i] : 0.0;                                     \
+      }                                                                                               \
+      {                                                                                               \
+         const double2 *src_ = reinterpret_cast<const double2 *> (fac_t + grp_base[GG]);              \
+         const int cnt2_ = (int) (((size_t) (2 * P + 1) * n_ml * gw * sizeof (float)) >> 4);          \
+         _Pragma ("unroll")                                                                           \
+         for (int u = 0; u < LANES_PIPE_BATCH; u++) {                                                 \
+            const int i = lane + u * NKP_WAVE;                                                        \
+            n_t[u] = (i < cnt2_) ? src_[i] : make_double2 (0.0, 0.0);                                 \
+         }                                                                                            \
+      }                                                                                               \
+   } while (0)
+
+   LANES_PREFETCH (g);
+   for (;;) {
+      // commit the prefetched group to LDS; it becomes the current one
+      const int nb = n_nb, ml = n_ml, R0 = n_R0, nrows = n_nrows, s = n_s, len = n_len;
+      double tz[8];
+      {
+         double2 *dst = reinterpret_cast<double2 *> (fl);
+         const int cnt2 = (int) (((size_t) (2 * P + 1) * ml * gw * sizeof (float)) >> 4);
+#pragma unroll
+         for (int u = 0; u < LANES_PIPE_BATCH; u++) {
+            const int i = lane + u * NKP_WAVE;
+            if (i < cnt2) dst[i] = n_t[u];
+         }
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            const int i = lane + u * NKP_WAVE;
+            tz[u] = n_tz[u];
+            if (i < nrows) lds[LDS_PAD (i)] = n_tr[u];
+         }
+      }
+      __syncthreads ();
+      const int gn = g + (int) gridDim.x;
+      const bool have_next = gn < g_end;
+      if (have_next) LANES_PREFETCH (gn);
+
+      if (lane < nb) {
+         const float *ft = fl + lane;
+         const int dstride = ml * gw;
+         double v[MAXL];
+#pragma unroll
+         for (int k = 0; k < MAXL; k++) v[k] = (k < len) ? lds[LDS_PAD (s + k)] : 0.0;
+#pragma unroll
+         for (int k0 = 0; k0 < MAXL; k0 += 8) {
+            if (k0 < ml) {
+#pragma unroll
+               for (int k = k0; k < k0 + 8; k++) {
+                  double y = v[k];
+#pragma unroll
+                  for (int q = P; q >= 1; q--)
+                     if (k - q >= 0) y -= (double) ft[(P - q) * dstride + k * gw] * v[k - q];
+                  v[k] = y;
+               }
+            }
+         }
+#pragma unroll
+         for (int k0 = MAXL - 8; k0 >= 0; k0 -= 8) {
+            if (k0 < ml) {
+#pragma unroll
+               for (int k = k0 + 7; k >= k0; k--) {
+                  double x = v[k];
+#pragma unroll
+                  for (int q = P; q >= 1; q--)
+                     if (k + q < MAXL) x -= (double) ft[(P + q) * dstride + k * gw] * v[k + q];
+                  x *= (double) ft[P * dstride + k * gw];
+                  v[k] = x;
+               }
+            }
+         }
+#pragma unroll
+         for (int k = 0; k < MAXL; k++)
+            if (k < len) lds[LDS_PAD (s + k)] = v[k];
+      }
+      __syncthreads ();
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         const int i = lane + u * NKP_WAVE;
+         if (i < nrows) z[(int64_t) R0 + i] = accumulate ? tz[u] + lds[LDS_PAD (i)] : lds[LDS_PAD (i)];
+      }
+      __syncthreads ();          // the LDS image is free again
+      if (!have_next) break;
+      g = gn;
+   }
+#undef LANES_PREFETCH
+}
+
 void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const double *r, double *z, int accumulate, hipStream_t st)
 {
    if (g1 <= g0) return;
    const size_t lds = (size_t) B.lds_doubles * sizeof (double);
+   {
+      // pipelined persistent variant: f32 factors, <= 64 levels, 8 columns per wave, band <= 2.  OFF unless
+      // NKP_COLPIPE_MIN=<groups> is set: it needs 256 VGPRs (one wave per SIMD), and with nothing to interleave the
+      // recurrence's own dependency stalls cost more than the hidden load latency saves -- 1 degree V-cycle 3.10 ms
+      // against 2.70 ms for the one-group-per-wave kernel (bit-identical results)
+      static int pipe_min = -1;
+      if (pipe_min < 0) { const char *e = getenv ("NKP_COLPIPE_MIN"); pipe_min = e ? atoi (e) : 0; }
+      if (B.fac_tf && B.max_len <= 64 && B.gw == 8 && B.P <= 2 && pipe_min > 0 && g1 - g0 >= pipe_min && lds <= 48 * 1024) {
+         int waves = 256 * 8;                         // two waves per SIMD fit the ~230 registers
+         if (waves > (g1 - g0 + 1) / 2) waves = (g1 - g0 + 1) / 2;
+         if (B.P == 1) hipLaunchKernelGGL ((colblock_apply_lanes_pipe_kernel<1>), dim3 (waves), dim3 (NKP_WAVE), lds, st, B.grp_nb, B.grp_maxlen, B.grp_base, g0, g1,
+                                           B.fac_tf, r, z, accumulate, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp);
+         else hipLaunchKernelGGL ((colblock_apply_lanes_pipe_kernel<2>), dim3 (waves), dim3 (NKP_WAVE), lds, st, B.grp_nb, B.grp_maxlen, B.grp_base, g0, g1,
+                                  B.fac_tf, r, z, accumulate, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp);
+         return;
+      }
+   }
 #define LANES_LAUNCH(PP)                                                                                                   \
    do {                                                                                                                    \
       if (B.max_len <= 64) LANES_LAUNCH2 (PP, 64);                                                                         \
