@@ -513,3 +513,27 @@ def test_cli_concurrent_right_hand_sides(tmp_path, golden_by_name):
     assert "2 in flight" in outs[1][1] and "in flight" not in outs[0][1]
     assert outs[0][0] == outs[1][0]
     assert outs[0][0] != open(g.tracer_path, "rb").read()
+
+
+def test_chained_cycles_option(medium, capfd):
+    """nkp_options.precond_steps: k multilevel cycles per Krylov iteration chained by defect correction against A.
+    Same answer, fewer iterations; the automatic choice is probed before the first solve and never hurts."""
+    p, blk = medium
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    b = np.random.default_rng(31).standard_normal(p.flat_len)
+    res = {}
+    for k in (1, 2, 3):
+        with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, precond_steps=k) as s:
+            assert s.get_int("precond_steps") == k
+            res[k] = s.solve(b)
+    for k in (2, 3):
+        assert res[k][1]["status"] == 0 and res[k][1]["iters"] < res[1][1]["iters"]
+        assert np.linalg.norm(res[k][0] - res[1][0]) / np.linalg.norm(res[1][0]) <= 1e-7
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, verbose=1) as s:      # automatic
+        x, info = s.solve(b)
+        assert info["status"] == 0 and info["iters"] <= res[1][1]["iters"]
+        assert s.get_int("precond_steps") in (1, 2)
+    assert "defect-correction probe" in capfd.readouterr().out
+    # block-Jacobi and no preconditioner stay single-step (iteration parity with the CPU port depends on it)
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, precond=solver.PRECOND_COLUMN_JACOBI, max_iters=5) as s:
+        assert s.get_int("precond_steps") == 1
