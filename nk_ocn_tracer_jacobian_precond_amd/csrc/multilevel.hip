@@ -30,7 +30,9 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -40,6 +42,33 @@ struct HostCsr {
    std::vector<int> rowptr, colind;
    std::vector<double> val;
 };
+
+// ---------------------------------------------------------------- host threads for the setup loops
+int setup_threads ()
+{
+   static int t = -1;
+   if (t < 0) {
+      const char *e = getenv ("NKP_SETUP_THREADS");
+      t = e ? atoi (e) : (int) std::min (16u, std::max (1u, std::thread::hardware_concurrency ()));
+      if (t < 1) t = 1;
+   }
+   return t;
+}
+
+// run fn (chunk, first_row, last_row) on contiguous row chunks, one host thread each
+template <class F>
+void for_row_chunks (int64_t n, F fn)
+{
+   int nt = setup_threads ();
+   if (n < 200000) nt = 1;
+   std::vector<std::thread> pool;
+   for (int c = 0; c < nt; c++) {
+      const int64_t r0 = n * c / nt, r1 = n * (c + 1) / nt;
+      if (nt == 1) fn (c, r0, r1);
+      else pool.emplace_back ([=] () { fn (c, r0, r1); });
+   }
+   for (std::thread &th : pool) th.join ();
+}
 
 // ---------------------------------------------------------------- low-order twin
 // L = A + D - diag(rowsum D), D_ij = max(0, -a_ij, -a_ji) for i, j in different columns
@@ -301,6 +330,9 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
               hipStream_t st, char *err, size_t errlen)
 {
 #define ML_FAIL(code, ...) do { snprintf (err, errlen, __VA_ARGS__); return (code); } while (0)
+   using clk = std::chrono::steady_clock;
+   auto secs = [] (clk::time_point a) { return std::chrono::duration<double> (clk::now () - a).count (); };
+   double t_low = 0.0, t_graph = 0.0, t_galerkin = 0.0, t_perm = 0.0, t_dev = 0.0;
    H.nu = nu < 1 ? 1 : nu;
    H.f32 = 1;                                     // level operators and factors stored in f32, arithmetic in f64
    if (const char *e = getenv ("NKP_ML_F32")) H.f32 = atoi (e) != 0;
@@ -326,7 +358,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       N.col_of.resize (n);
       for (int64_t c = 0; c < nblk; c++)
          for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.col_of[r] = (int) c;
-      build_low_order (n, rowptr, colind, val, N.col_of, N.L);
+      { auto t0 = clk::now (); build_low_order (n, rowptr, colind, val, N.col_of, N.L); t_low += secs (t0); }
       if (col_i && col_j) {
          N.gi.assign (col_i, col_i + nblk);
          N.gj.assign (col_j, col_j + nblk);
@@ -339,7 +371,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       Nat &N = nat[l];
       const int ncol = (int) N.blk_start.size () - 1;
       ColGraph G;
-      build_col_graph (N.L, N.blk_start, N.col_of, G);
+      { auto t0 = clk::now (); build_col_graph (N.L, N.blk_start, N.col_of, G); t_graph += secs (t0); }
       const bool geo = !N.gi.empty ();
       if (geo) {
          N.colour.resize (ncol);
@@ -417,7 +449,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       N.cmap.resize (N.L.n);
       for (int c = 0; c < ncol; c++)
          for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.cmap[r] = C.blk_start[N.agg[c]] + (r - N.blk_start[c]);
-      galerkin (N.L, N.cmap, ncr, C.L);
+      { auto t0 = clk::now (); galerkin (N.L, N.cmap, ncr, C.L); t_galerkin += secs (t0); }
       C.col_of.resize (ncr);
       for (int a = 0; a < n2; a++)
          for (int r = C.blk_start[a]; r < C.blk_start[a + 1]; r++) C.col_of[r] = a;
@@ -436,16 +468,21 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       // permuted CSR: row new = perm[new]; columns relabelled through inv, then sorted
       std::vector<int> prow (nl + 1, 0), pcol (N.L.colind.size ());
       std::vector<double> pval (N.L.colind.size ());
-      std::vector<std::pair<int, double>> tmp;
-      for (int64_t i = 0; i < nl; i++) {
-         const int o = N.perm[i];
-         tmp.clear ();
-         for (int e = N.L.rowptr[o]; e < N.L.rowptr[o + 1]; e++) tmp.emplace_back (N.inv[N.L.colind[e]], N.L.val[e]);
-         std::sort (tmp.begin (), tmp.end ());
-         int q = prow[i];
-         for (auto &t : tmp) { pcol[q] = t.first; pval[q] = t.second; q++; }
-         prow[i + 1] = q;
-      }
+      auto t_perm0 = clk::now ();
+      for (int64_t i = 0; i < nl; i++) prow[i + 1] = prow[i] + (N.L.rowptr[N.perm[i] + 1] - N.L.rowptr[N.perm[i]]);
+      for_row_chunks (nl, [&] (int, int64_t i0, int64_t i1) {
+         std::vector<std::pair<int, double>> tmp;
+         for (int64_t i = i0; i < i1; i++) {
+            const int o = N.perm[i];
+            tmp.clear ();
+            for (int e = N.L.rowptr[o]; e < N.L.rowptr[o + 1]; e++) tmp.emplace_back (N.inv[N.L.colind[e]], N.L.val[e]);
+            std::sort (tmp.begin (), tmp.end ());
+            int q = prow[i];
+            for (auto &t : tmp) { pcol[q] = t.first; pval[q] = t.second; q++; }
+         }
+      });
+      t_perm += secs (t_perm0);
+      auto t_dev0 = clk::now ();
       // permuted column blocks
       std::vector<int> pblk;
       pblk.reserve (ncol + 1);
@@ -551,8 +588,13 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       if (verbose)
          printf ("(%d) multilevel: level %d: %lld rows, %lld entries, %d columns (%d + %d by colour)%s\n", rank, l, (long long) nl,
                  (long long) prow[nl], ncol, N.ncol0, ncol - N.ncol0, l == nlev - 1 ? ", dense solve" : "");
+      t_dev += secs (t_dev0);
    }
-   if (verbose) fflush (stdout);
+   if (verbose) {
+      printf ("(%d) multilevel setup: %.2f s low-order twin, %.2f s column graphs, %.2f s Galerkin products, %.2f s colour-major permutation, "
+              "%.2f s uploads + factorisation + lane layouts\n", rank, t_low, t_graph, t_galerkin, t_perm, t_dev);
+      fflush (stdout);
+   }
    return 0;
 #undef ML_FAIL
 }
