@@ -80,7 +80,7 @@ typedef struct nkp_options {
                             the f64 Z vectors, the true residual is recomputed in f64 at every restart).  Default 0:
                             with a single Gram-Schmidt pass the f32 basis can double the iteration count. */
    int precond_steps;    /* preconditioner cycles per Krylov iteration, chained by defect correction against A:
-                            z = M r; z += M (r - A z); ...  0 = automatic (multilevel: 2, 3 from 6 M rows; else 1)      */
+                            z = M r; z += M (r - A z); ...  0 = automatic (multilevel: 2 from 2 M rows, 3 from 6 M; else 1) */
    int reserved[5];
    /* multilevel, optional: grid position (i, j) of every water-column block, nblk entries each
     * (tracer_state_ind_to_i/_j at the block's first row, reference src/matrix.c:322-329).  With

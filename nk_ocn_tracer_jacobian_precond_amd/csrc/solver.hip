@@ -295,7 +295,8 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    s->m = opt.restart;
    // cycles per preconditioner application (defect correction against A between them): measured 1 degree 772 its /
    // 3.17 s with one, 410 / 2.93 s with two, 307 / 3.02 s with three; 0.5 degree 3190 / 24.8 s, 1373 / 17.7 s, 805 / 14.5 s
-   s->precond_steps = (opt.precond == NKP_PRECOND_MULTILEVEL) ? (n >= 6000000 ? 3 : 2) : 1;
+   // small systems are latency-bound and gain nothing (3 degree: 160 instead of 250 iterations but 0.38 s instead of 0.33 s)
+   s->precond_steps = (opt.precond == NKP_PRECOND_MULTILEVEL) ? (n >= 6000000 ? 3 : n >= 2000000 ? 2 : 1) : 1;
    s->steps_auto = s->precond_steps > 1;
    if (opt.precond_steps > 0) { s->precond_steps = opt.precond_steps; s->steps_auto = false; }
    { const char *e = getenv ("NKP_PRECOND_STEPS"); if (e && atoi (e) > 0) { s->precond_steps = atoi (e); s->steps_auto = false; } }
@@ -693,10 +694,12 @@ static int backward_error (nkp_solver *s, double *berr)
    return NKP_OK;
 }
 
-// Defect correction z += M (r - A z) only helps when the stationary iteration it repeats contracts.  Eight steps of
-// the power method on E = I - M A from a fixed pseudo-random start (11 ms at 1 degree) estimate its spectral radius
-// from below; at 0.97 or more -- seen on badly scaled coupled-tracer matrices -- the solver stays with one cycle
-// per iteration.  fgmres() has a run-time guard for what this lower bound misses.
+// Chaining cycles by defect correction, z += M (r - A z), repeats the stationary iteration with E = I - M A.  Inside
+// FGMRES it pays even when E expands mildly (0.5 degree: growth 1.30 per step, yet 805 iterations / 14.5 s with three
+// cycles against 3190 / 24.8 s with one), but a strongly expanding E makes the chained operator so ill-conditioned
+// that rounding wins (seen on a badly scaled coupled-tracer matrix).  Eight steps of the power method from a fixed
+// pseudo-random start (25 ms at 1 degree) estimate the growth from below; at 1.6 or more the solver stays with one
+// cycle per iteration.  fgmres() has a run-time guard for what this estimate misses.
 static int probe_defect_correction (nkp_solver *s)
 {
    s->steps_auto = false;
@@ -727,11 +730,11 @@ static int probe_defect_correction (nkp_solver *s)
       if (!(growth > 0.0) || !(growth == growth)) { rho = (growth == 0.0) ? rho : 2.0; break; }
       launch_axpby (0.0, v, 1.0 / growth, v, s->n, s->stream);
    }
-   if (!(rho < 0.97)) {
+   if (!(rho < 1.6)) {
       msg (s, 1, "defect-correction probe: |I - M A| grows by %.3f per step; one preconditioner cycle per iteration\n", rho);
       s->precond_steps = 1;
    } else
-      msg (s, 1, "defect-correction probe: contraction %.3f; %d preconditioner cycles per iteration\n", rho, s->precond_steps);
+      msg (s, 1, "defect-correction probe: |I - M A| changes by %.3f per step; %d preconditioner cycles per iteration\n", rho, s->precond_steps);
    return NKP_OK;
 }
 
