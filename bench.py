@@ -182,6 +182,7 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             s = None
+            n_global = p.flat_len                          # replicas of the single-tracer problem
             mode = "FALLBACK: one replica of the solve per rank (distributed setup failed, see stderr)"
     if (world == 1 and not a.force_dist) or s is None:
         s = solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, **kw)
