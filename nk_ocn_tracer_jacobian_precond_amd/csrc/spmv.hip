@@ -356,11 +356,15 @@ static void launch_range (const CsrDev &A, int rb0, int cnt, const double *x, do
    if (cnt <= 0) return;
    const int per_xcd = (cnt + 7) / 8;
    if (spmv_variant () == 4 && cnt >= spmv_pipe_min ()) {
-      // runs of ~3 row blocks per workgroup: long enough to pipeline, short enough to balance the tail
-      // (same-process A/B at 1 degree: 6 per CU 199 us, 24 per CU 184 us, 48 per CU 177 us)
+      // how many row blocks one workgroup walks (NKP_SPMV_RUN) and how many workgroups per CU at most (NKP_SPMV_WGS).
+      // Same-process A/B at 1 degree, first with runs of >= 3: 6 per CU 199 us, 24 per CU 184 us, 48 per CU 177 us; then
+      // runs of 1 with 160-256 per CU: SpMV -1..2 %, V-cycle 2.71 -> 2.63 ms, Arnoldi step (j = 100) 7.02 -> 6.86 ms on
+      // two repeats -- enough workgroups in flight hide the stream latency as well as the in-workgroup prefetch does
       static int per_cu = -1;
-      if (per_cu < 0) { const char *e = getenv ("NKP_SPMV_WGS"); per_cu = (e && atoi (e) > 0) ? atoi (e) : 48; }
-      int wgs = cnt / 3;
+      if (per_cu < 0) { const char *e = getenv ("NKP_SPMV_WGS"); per_cu = (e && atoi (e) > 0) ? atoi (e) : 256; }
+      static int run_len = -1;
+      if (run_len < 0) { const char *e = getenv ("NKP_SPMV_RUN"); run_len = (e && atoi (e) > 0) ? atoi (e) : 1; }
+      int wgs = cnt / run_len;
       if (wgs > 256 * per_cu) wgs = 256 * per_cu;
       wgs &= ~7;
       if (wgs < 8) wgs = 8;
