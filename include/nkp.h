@@ -216,6 +216,18 @@ int nkp_dist_plan_host (int64_t m_loc, int64_t nnz_loc, const int32_t *rowptr_lo
                         int rank, int nranks, const int64_t *starts, int32_t *colind_ext, int32_t *halo_rows,
                         int64_t *n_halo, int32_t *need_counts);
 
+/* Host-only planning step of the multilevel preconditioner inside nkp_create, exposed so the aggregation logic can
+ * be tested without a GPU: builds the low-order twin, the coarse cells of every level (geometric groups split by
+ * lateral connectivity) and the Galerkin products, and reports
+ *   *n_levels, rows[l] (l < *n_levels), and for every level l < *n_levels - 1, concatenated in level order:
+ *   cmap   : coarse row (level l+1 numbering) of every row of level l            (sum of rows[0 .. n_levels-2] entries)
+ *   col_of : column block of every row of level l+1                              (sum of rows[1 .. n_levels-1] entries)
+ * `capacity` bounds both output arrays (entries).  col_i / col_j as in nkp_options.  Returns 0, NKP_EINVAL, or NKP_ENOMEM
+ * when the capacity is too small. */
+int nkp_ml_plan_host (int64_t n, const int32_t *rowptr, const int32_t *colind, const double *val, const int32_t *blk_start,
+                      int64_t nblk, const int32_t *col_i, const int32_t *col_j, int coupled_tracer_cnt, int max_levels,
+                      int coarsest_rows, int64_t capacity, int *n_levels, int64_t *rows, int32_t *cmap, int32_t *col_of);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@
 // Setup is host code (O(nnz)); every cycle runs on the device.
 #include "nkp_dev.h"
 #include "multilevel.h"
+#include "../../include/nkp.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -223,6 +224,176 @@ void two_colour (int ncol, const ColGraph &G, std::vector<int> &colour)
    }
 }
 
+
+// ---------------------------------------------------------------- split aggregates (geometric groups, connectivity-aware)
+// A group of columns (2 x 2 or 4 x 4 in (i, j)) is NOT turned into one coarse column blindly: at every depth k the
+// members that are wet at k form one coarse cell per CONNECTED set (lateral couplings of the level operator between
+// members), because a piecewise-constant cell over mutually uncoupled water (two sides of a ridge, a deep pocket
+// next to open water) cannot represent the near-kernel of the operator -- it is constant per connected piece, not per
+// group -- and neither the column smoother nor any coarser level then removes that error (measured: the two-grid
+// iteration with an exact coarse solve needs 88 Krylov steps at a 0.25-degree cell Courant number, 21 with the split).
+//  * same-depth connected sets of at most `pocket` cells are merged into one coarse cell even across groups (a deep
+//    pocket is a strongly coupled cluster hanging on weak vertical diffusion: it must become ONE unknown);
+//  * the sets are threaded through depth into coarse columns: the child set with the largest overlap continues its
+//    parent's column, every other child starts a stub column (first depth > 0) at the same (i, j);
+//  * a stub of the fine level that no outside row feels (every coupling into it is < tau x that row's diagonal) is a
+//    leaf: the column solve makes it follow its neighbours exactly, so it is absorbed into the coarse cell it hangs
+//    from instead of surviving as an unknown on every coarser level.
+// Rows keep their depth: row r of column c sits at depth ktop[c] + (r - blk_start[c]).
+struct SplitResult {
+   std::vector<int> cmap;                     // fine row -> coarse row
+   std::vector<int> blk_start, ktop, gi, gj, gt;   // coarse columns
+   int absorbed = 0, stubs = 0;
+};
+
+struct UnionFind {
+   std::vector<int> p;
+   explicit UnionFind (size_t n) : p (n) { std::iota (p.begin (), p.end (), 0); }
+   int find (int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+   void unite (int a, int b) { a = find (a); b = find (b); if (a != b) { if (a < b) p[b] = a; else p[a] = b; } }   // root = lowest row
+};
+
+void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const std::vector<int> &col_of, const std::vector<int> &ktop,
+                      const std::vector<int> &group, const std::vector<int> &ggi, const std::vector<int> &ggj, const std::vector<int> &ggt,
+                      const std::vector<int> &col_t, int pocket, double theta, double tau, SplitResult &R)
+{
+   const int64_t n = L.n;
+   const int ncol = (int) blk_start.size () - 1;
+   auto depth = [&] (int r) { const int c = col_of[r]; return ktop[c] + (r - blk_start[c]); };
+   auto row_at = [&] (int c, int k) -> int { const int r = blk_start[c] + (k - ktop[c]); return (k >= ktop[c] && r < blk_start[c + 1]) ? r : -1; };
+   // per row: diagonal and strongest lateral coupling; per column: how strongly any outside row of the same tracer feels it
+   std::vector<double> diag (n, 0.0), rowmax (n, 0.0), felt (ncol, 0.0), best (ncol, -1.0);
+   std::vector<int> anchor (ncol, -1);
+   for (int64_t r = 0; r < n; r++)
+      for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++)
+         if (L.colind[e] == r) diag[r] = fabs (L.val[e]);
+   for (int64_t r = 0; r < n; r++) {
+      const int c = col_of[r];
+      for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++) {
+         const int j = L.colind[e], c2 = col_of[j];
+         if (c2 == c || col_t[c2] != col_t[c]) continue;
+         const double v = fabs (L.val[e]);
+         if (v > rowmax[r]) rowmax[r] = v;
+         const double f = diag[r] > 0.0 ? v / diag[r] : 1.0e300;
+         if (f > felt[c2]) felt[c2] = f;
+         if (v >= best[c]) { best[c] = v; anchor[c] = j; }          // strongest coupling of the column, ties -> later entry
+      }
+   }
+   std::vector<char> dang (ncol, 0);
+   for (int c = 0; c < ncol; c++) dang[c] = (tau > 0.0 && ktop[c] > 0 && felt[c] < tau && anchor[c] >= 0);
+   {
+      std::vector<char> bad (ncol, 0);
+      for (int c = 0; c < ncol; c++) bad[c] = dang[c] && dang[col_of[anchor[c]]];
+      for (int c = 0; c < ncol; c++) if (bad[c]) dang[c] = 0;
+   }
+   // lateral edges between cells of the same depth
+   struct Edge { int a, b; bool same; };
+   std::vector<Edge> edges;
+   edges.reserve ((size_t) n * 2);
+   for (int64_t r = 0; r < n; r++) {
+      const int c = col_of[r];
+      if (dang[c]) continue;
+      const int k = depth ((int) r);
+      for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++) {
+         const int j = L.colind[e], c2 = col_of[j];
+         if (c2 == c || dang[c2] || col_t[c2] != col_t[c]) continue;
+         const int dk = depth (j) - k;
+         if (dk < -1 || dk > 1) continue;
+         if (fabs (L.val[e]) < theta * rowmax[r]) continue;
+         const int t = row_at (c2, k);
+         if (t < 0) continue;
+         edges.push_back ({ (int) r, t, group[c] == group[c2] });
+      }
+   }
+   UnionFind U (n);
+   if (pocket > 0) {
+      UnionFind U0 (n);
+      for (const Edge &e : edges) U0.unite (e.a, e.b);
+      std::vector<int> size (n, 0);
+      for (int64_t r = 0; r < n; r++) size[U0.find ((int) r)]++;
+      for (const Edge &e : edges)
+         if (e.same || size[U0.find (e.a)] <= pocket) U.unite (e.a, e.b);
+   } else
+      for (const Edge &e : edges) if (e.same) U.unite (e.a, e.b);
+   edges.clear ();
+   edges.shrink_to_fit ();
+   // components numbered in order of their lowest row
+   std::vector<int> comp (n, -1);
+   int ncomp = 0;
+   for (int64_t r = 0; r < n; r++) {
+      const int root = U.find ((int) r);
+      if (comp[root] < 0) comp[root] = ncomp++;       // root is the lowest row of its set, so it is met first
+      comp[r] = comp[root];
+   }
+   std::vector<int> kcomp (ncomp, 0);
+   for (int64_t r = 0; r < n; r++) kcomp[comp[r]] = depth ((int) r);
+   // overlaps between a set and the sets directly below it
+   std::vector<std::pair<int, int>> pc;
+   pc.reserve (n);
+   for (int c = 0; c < ncol; c++)
+      for (int r = blk_start[c]; r + 1 < blk_start[c + 1]; r++) pc.emplace_back (comp[r], comp[r + 1]);
+   std::sort (pc.begin (), pc.end ());
+   std::vector<int> bestpar (ncomp, -1), bestpar_cnt (ncomp, 0), bestchi (ncomp, -1), bestchi_cnt (ncomp, 0);
+   for (size_t q = 0; q < pc.size ();) {
+      size_t q2 = q;
+      while (q2 < pc.size () && pc[q2] == pc[q]) q2++;
+      const int par = pc[q].first, chi = pc[q].second, cnt = (int) (q2 - q);
+      // pairs arrive sorted by (parent, child): a strict '>' keeps the lowest id on ties
+      if (cnt > bestpar_cnt[chi]) { bestpar_cnt[chi] = cnt; bestpar[chi] = par; }
+      if (cnt > bestchi_cnt[par]) { bestchi_cnt[par] = cnt; bestchi[par] = chi; }
+      q = q2;
+   }
+   // coarse columns: sets in order of depth, then of id
+   std::vector<int> order (ncomp);
+   std::iota (order.begin (), order.end (), 0);
+   std::stable_sort (order.begin (), order.end (), [&] (int a, int b) { return kcomp[a] < kcomp[b]; });
+   std::vector<int> ccol (ncomp, -1), cc_ktop, cc_len;
+   for (int id : order) {
+      const int par = bestpar[id];
+      if (par >= 0 && bestchi[par] == id) {
+         ccol[id] = ccol[par];
+         cc_len[ccol[id]]++;
+      } else {
+         ccol[id] = (int) cc_ktop.size ();
+         cc_ktop.push_back (kcomp[id]);
+         cc_len.push_back (1);
+      }
+   }
+   // absorbed stubs own no coarse column: drop the (now empty) columns their sets opened
+   const int nraw = (int) cc_ktop.size ();
+   // a coarse column sits at the (i, j) of the group of its lowest fine row (a merged pocket can span groups)
+   std::vector<char> used (nraw, 0);
+   std::vector<int> cc_group (nraw, 0);
+   for (int64_t r = 0; r < n; r++)
+      if (!dang[col_of[r]] && !used[ccol[comp[r]]]) { used[ccol[comp[r]]] = 1; cc_group[ccol[comp[r]]] = group[col_of[r]]; }
+   std::vector<int> newid (nraw, -1);
+   int ncc = 0;
+   for (int q = 0; q < nraw; q++) if (used[q]) newid[q] = ncc++;
+   R.blk_start.assign (ncc + 1, 0);
+   R.ktop.resize (ncc); R.gi.resize (ncc); R.gj.resize (ncc); R.gt.resize (ncc);
+   for (int q = 0; q < nraw; q++) {
+      if (!used[q]) continue;
+      const int a = newid[q];
+      R.blk_start[a + 1] = cc_len[q];
+      R.ktop[a] = cc_ktop[q];
+      R.gi[a] = ggi[cc_group[q]]; R.gj[a] = ggj[cc_group[q]]; R.gt[a] = ggt[cc_group[q]];
+      if (cc_ktop[q] > 0) R.stubs++;
+   }
+   for (int a = 0; a < ncc; a++) R.blk_start[a + 1] += R.blk_start[a];
+   R.cmap.assign (n, -1);
+   for (int64_t r = 0; r < n; r++) {
+      if (dang[col_of[r]]) continue;
+      const int a = newid[ccol[comp[r]]];
+      R.cmap[r] = R.blk_start[a] + (depth ((int) r) - R.ktop[a]);
+   }
+   for (int c = 0; c < ncol; c++) {
+      if (!dang[c]) continue;
+      R.absorbed++;
+      const int target = R.cmap[anchor[c]];
+      for (int r = blk_start[c]; r < blk_start[c + 1]; r++) R.cmap[r] = target;
+   }
+}
+
 // Galerkin product with a piecewise-constant P given as fine row -> coarse row
 void galerkin (const HostCsr &L, const std::vector<int> &cmap, int64_t nc, HostCsr &C)
 {
@@ -322,40 +493,33 @@ bool upload_padded (T **dst, const T *src, size_t count, size_t pad, size_t *byt
    return true;
 }
 
-}  // namespace
+// ---------------------------------------------------------------- natural-order data of every level (host)
+struct Nat {
+   HostCsr L;
+   std::vector<int> blk_start, col_of, colour, agg;   // per column: colour, aggregate id
+   std::vector<int> cmap;                            // fine row -> coarse row (natural orders)
+   std::vector<int> perm, inv;                       // perm[new] = old ; inv[old] = new  (colour-major)
+   std::vector<int> gi, gj, gt;                      // optional grid position / tracer of every column
+   std::vector<int> ktop;                            // depth of the first row of every column (0 except for stub columns)
+   int nagg = 0;
+   int ncol0 = 0;                                    // columns of colour 0
+};
 
-// ================================================================ setup
-int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, const double *val,
-              const int *blk_start_in, int64_t nblk, const int *col_i, const int *col_j, int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
-              hipStream_t st, char *err, size_t errlen)
+struct SetupTimes { double low = 0.0, graph = 0.0, galerkin = 0.0; };
+
+// twin, colouring, aggregation and Galerkin product of every level; host only (no HIP call)
+void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, const int *colind, const double *val, const int *blk_start_in, int64_t nblk,
+                       const int *col_i, const int *col_j, int tracer_cnt, int max_levels, int coarsest_rows, int verbose, int rank, SetupTimes &T)
 {
-#define ML_FAIL(code, ...) do { snprintf (err, errlen, __VA_ARGS__); return (code); } while (0)
    using clk = std::chrono::steady_clock;
    auto secs = [] (clk::time_point a) { return std::chrono::duration<double> (clk::now () - a).count (); };
-   double t_low = 0.0, t_graph = 0.0, t_galerkin = 0.0, t_perm = 0.0, t_dev = 0.0;
-   H.nu = nu < 1 ? 1 : nu;
-   H.f32 = 1;                                     // level operators and factors stored in f32, arithmetic in f64
-   if (const char *e = getenv ("NKP_ML_F32")) H.f32 = atoi (e) != 0;
-   H.nu_coarse = H.nu;
-   if (const char *e = getenv ("NKP_ML_SMOOTH_COARSE")) { const int v = atoi (e); if (v >= 1) H.nu_coarse = v; }
-   if (const char *e = getenv ("NKP_ML_COARSE_FROM")) { const int v = atoi (e); if (v >= 1) H.coarse_from = v; }
-   if (max_levels <= 0) max_levels = 12;
-
-   // ---- natural-order data of every level (host)
-   struct Nat {
-      HostCsr L;
-      std::vector<int> blk_start, col_of, colour, agg;   // per column: colour, aggregate id
-      std::vector<int> cmap;                            // fine row -> coarse row (natural orders)
-      std::vector<int> perm, inv;                       // perm[new] = old ; inv[old] = new  (colour-major)
-      std::vector<int> gi, gj, gt;                      // optional grid position / tracer of every column
-      int nagg = 0;
-      int ncol0 = 0;                                    // columns of colour 0
-   };
-   std::vector<Nat> nat (1);
+   double &t_low = T.low, &t_graph = T.graph, &t_galerkin = T.galerkin;
+   nat.assign (1, Nat ());
    {
       Nat &N = nat[0];
       N.blk_start.assign (blk_start_in, blk_start_in + nblk + 1);
       N.col_of.resize (n);
+      N.ktop.assign (nblk, 0);
       for (int64_t c = 0; c < nblk; c++)
          for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.col_of[r] = (int) c;
       { auto t0 = clk::now (); build_low_order (n, rowptr, colind, val, N.col_of, N.L); t_low += secs (t0); }
@@ -437,23 +601,105 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          for (int c = 0; c < ncol; c++) N.agg[c] = g2[g1[c]];
       }
       N.nagg = n2;
-      if (n2 >= ncol) break;                            // no coarsening possible
-      // coarse columns: length = longest member
-      std::vector<int> clen (n2, 0);
-      for (int c = 0; c < ncol; c++) clen[N.agg[c]] = std::max (clen[N.agg[c]], N.blk_start[c + 1] - N.blk_start[c]);
       Nat C;
-      C.gi.swap (cgi); C.gj.swap (cgj); C.gt.swap (cgt);
-      C.blk_start.assign (n2 + 1, 0);
-      for (int a = 0; a < n2; a++) C.blk_start[a + 1] = C.blk_start[a] + clen[a];
-      const int64_t ncr = C.blk_start[n2];
-      N.cmap.resize (N.L.n);
-      for (int c = 0; c < ncol; c++)
-         for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.cmap[r] = C.blk_start[N.agg[c]] + (r - N.blk_start[c]);
+      int64_t ncr = 0;
+      static int split = -1, pocket = 16;
+      static double theta = 0.0, tau = 0.01;
+      if (split < 0) {
+         const char *e = getenv ("NKP_ML_SPLIT");
+         split = e ? atoi (e) != 0 : 1;
+         if ((e = getenv ("NKP_ML_POCKET"))) pocket = atoi (e);
+         if ((e = getenv ("NKP_ML_THETA"))) theta = atof (e);
+         if ((e = getenv ("NKP_ML_TAU"))) tau = atof (e);
+      }
+      if (geo && split) {
+         // connectivity-aware coarse cells inside the geometric groups (see split_aggregate)
+         auto t0 = clk::now ();
+         SplitResult R;
+         split_aggregate (N.L, N.blk_start, N.col_of, N.ktop, N.agg, cgi, cgj, cgt, N.gt, pocket, theta, tau, R);
+         t_graph += secs (t0);
+         ncr = R.blk_start.back ();
+         if (ncr >= N.L.n) break;                       // no coarsening possible
+         if (verbose)
+            printf ("(%d) multilevel: level %d -> %d: %d columns in %d groups -> %d coarse columns (%d stubs), %d leaf stubs absorbed\n", rank, l, l + 1, ncol, n2,
+                    (int) R.blk_start.size () - 1, R.stubs, R.absorbed);
+         n2 = (int) R.blk_start.size () - 1;
+         N.cmap.swap (R.cmap);
+         C.blk_start.swap (R.blk_start);
+         C.ktop.swap (R.ktop);
+         C.gi.swap (R.gi); C.gj.swap (R.gj); C.gt.swap (R.gt);
+      } else {
+         if (n2 >= ncol) break;                         // no coarsening possible
+         // coarse columns: length = longest member
+         std::vector<int> clen (n2, 0);
+         for (int c = 0; c < ncol; c++) clen[N.agg[c]] = std::max (clen[N.agg[c]], N.blk_start[c + 1] - N.blk_start[c]);
+         C.gi.swap (cgi); C.gj.swap (cgj); C.gt.swap (cgt);
+         C.blk_start.assign (n2 + 1, 0);
+         C.ktop.assign (n2, 0);
+         for (int a = 0; a < n2; a++) C.blk_start[a + 1] = C.blk_start[a] + clen[a];
+         ncr = C.blk_start[n2];
+         N.cmap.resize (N.L.n);
+         for (int c = 0; c < ncol; c++)
+            for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.cmap[r] = C.blk_start[N.agg[c]] + (r - N.blk_start[c]);
+      }
       { auto t0 = clk::now (); galerkin (N.L, N.cmap, ncr, C.L); t_galerkin += secs (t0); }
       C.col_of.resize (ncr);
       for (int a = 0; a < n2; a++)
          for (int r = C.blk_start[a]; r < C.blk_start[a + 1]; r++) C.col_of[r] = a;
       nat.push_back (std::move (C));
+   }
+
+}
+
+}  // namespace
+
+// ================================================================ host-only plan (tests)
+extern "C" int nkp_ml_plan_host (int64_t n, const int32_t *rowptr, const int32_t *colind, const double *val, const int32_t *blk_start, int64_t nblk,
+                                 const int32_t *col_i, const int32_t *col_j, int coupled_tracer_cnt, int max_levels, int coarsest_rows, int64_t capacity,
+                                 int *n_levels, int64_t *rows, int32_t *cmap, int32_t *col_of)
+{
+   if (n <= 0 || !rowptr || !colind || !val || !blk_start || nblk <= 0 || !n_levels || !rows || !cmap || !col_of) return NKP_EINVAL;
+   if (max_levels <= 0) max_levels = 12;
+   std::vector<Nat> nat;
+   SetupTimes T;
+   build_nat_levels (nat, n, rowptr, colind, val, blk_start, nblk, col_i, col_j, coupled_tracer_cnt, max_levels, coarsest_rows, 0, 0, T);
+   *n_levels = (int) nat.size ();
+   int64_t qc = 0, qo = 0;
+   for (size_t l = 0; l < nat.size (); l++) {
+      rows[l] = nat[l].L.n;
+      if (l + 1 < nat.size ()) {
+         if (qc + nat[l].L.n > capacity || qo + nat[l + 1].L.n > capacity) return NKP_ENOMEM;
+         std::copy (nat[l].cmap.begin (), nat[l].cmap.end (), cmap + qc);
+         std::copy (nat[l + 1].col_of.begin (), nat[l + 1].col_of.end (), col_of + qo);
+         qc += nat[l].L.n;
+         qo += nat[l + 1].L.n;
+      }
+   }
+   return 0;
+}
+
+// ================================================================ setup
+int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, const double *val,
+              const int *blk_start_in, int64_t nblk, const int *col_i, const int *col_j, int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
+              hipStream_t st, char *err, size_t errlen)
+{
+#define ML_FAIL(code, ...) do { snprintf (err, errlen, __VA_ARGS__); return (code); } while (0)
+   using clk = std::chrono::steady_clock;
+   auto secs = [] (clk::time_point a) { return std::chrono::duration<double> (clk::now () - a).count (); };
+   double t_low = 0.0, t_graph = 0.0, t_galerkin = 0.0, t_perm = 0.0, t_dev = 0.0;
+   H.nu = nu < 1 ? 1 : nu;
+   H.f32 = 1;                                     // level operators and factors stored in f32, arithmetic in f64
+   if (const char *e = getenv ("NKP_ML_F32")) H.f32 = atoi (e) != 0;
+   H.nu_coarse = H.nu;
+   if (const char *e = getenv ("NKP_ML_SMOOTH_COARSE")) { const int v = atoi (e); if (v >= 1) H.nu_coarse = v; }
+   if (const char *e = getenv ("NKP_ML_COARSE_FROM")) { const int v = atoi (e); if (v >= 1) H.coarse_from = v; }
+   if (max_levels <= 0) max_levels = 12;
+
+   std::vector<Nat> nat;
+   {
+      SetupTimes T;
+      build_nat_levels (nat, n, rowptr, colind, val, blk_start_in, nblk, col_i, col_j, tracer_cnt, max_levels, coarsest_rows, verbose, rank, T);
+      t_low = T.low; t_graph = T.graph; t_galerkin = T.galerkin;
    }
 
    // ---- device levels in colour-major order

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "nkp_spmv", "nkp_spmv_device", "nkp_precond_apply", "nkp_multi_dot", "nkp_time_kernel",
     "nkp_get_int", "nkp_set_stream", "nkp_destroy", "nkp_last_error", "nkp_comm_unique_id",
     "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host", "nkp_set_device",
-    "nkp_gather_root", "nkp_clone",
+    "nkp_gather_root", "nkp_clone", "nkp_ml_plan_host",
 ]
 
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
@@ -99,9 +99,42 @@ def load_library(path=None):
     lib.nkp_clone.argtypes = [vp, C.POINTER(vp)]
     lib.nkp_dist_plan_host.argtypes = [C.c_int64, C.c_int64, i32p, i32p, C.c_int, C.c_int, C.POINTER(C.c_int64), i32p, i32p,
                                        C.POINTER(C.c_int64), i32p]
+    lib.nkp_ml_plan_host.argtypes = [C.c_int64, i32p, i32p, f64p, i32p, C.c_int64, i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int64), i32p, i32p]
     if path == HIP_LIB_PATH:
         _lib = lib
     return lib
+
+
+def ml_plan_host(rowptr, colind, val, blk_start, col_i=None, col_j=None, coupled_tracer_cnt=1, max_levels=0, coarsest_rows=1500):
+    """nkp_ml_plan_host: the coarse cells of every level of the multilevel preconditioner (host only, no GPU needed).
+    Returns (rows per level, [cmap of level l -> l+1], [column block of every row of level l+1])."""
+    lib = load_library()
+    rowptr = np.ascontiguousarray(rowptr, np.int32)
+    colind = np.ascontiguousarray(colind, np.int32)
+    val = np.ascontiguousarray(val, np.float64)
+    blk_start = np.ascontiguousarray(blk_start, np.int32)
+    n = rowptr.size - 1
+    ip = lambda a: None if a is None else _p(np.ascontiguousarray(a, np.int32), C.c_int32)
+    ci = None if col_i is None else np.ascontiguousarray(col_i, np.int32)
+    cj = None if col_j is None else np.ascontiguousarray(col_j, np.int32)
+    cap = 2 * n + 64
+    cmap, colof = np.empty(cap, np.int32), np.empty(cap, np.int32)
+    rows = np.zeros(64, np.int64)
+    nlev = C.c_int()
+    rc = lib.nkp_ml_plan_host(n, _p(rowptr, C.c_int32), _p(colind, C.c_int32), _p(val, C.c_double), _p(blk_start, C.c_int32), blk_start.size - 1,
+                              None if ci is None else _p(ci, C.c_int32), None if cj is None else _p(cj, C.c_int32), coupled_tracer_cnt, max_levels,
+                              coarsest_rows, cap, C.byref(nlev), _p(rows, C.c_int64), _p(cmap, C.c_int32), _p(colof, C.c_int32))
+    if rc != 0:
+        raise NkpError(rc, "nkp_ml_plan_host failed")
+    rows = rows[:nlev.value]
+    cmaps, colofs, qc, qo = [], [], 0, 0
+    for l in range(nlev.value - 1):
+        cmaps.append(cmap[qc:qc + rows[l]].copy())
+        colofs.append(colof[qo:qo + rows[l + 1]].copy())
+        qc += rows[l]
+        qo += rows[l + 1]
+    return rows, cmaps, colofs
 
 
 def default_options(**overrides):

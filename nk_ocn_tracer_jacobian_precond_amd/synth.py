@@ -12,7 +12,10 @@ const/centred/donor/upwind3 assembly paths:
     upwind3 = QUICK weights 0.75/0.375/-0.125 with the 0.625 land fallback
     (src/matrix.c:1610-1690), diagonal = -sum(off-diagonals) (adv_enforce_divfree, :2195-2196)
   * hmix const: ah*HTE/HUS/TAREA*dt (src/matrix.c:2656-2678); "isop" adds 8 k+-1 x E/W/N/S
-    cross terms on the pattern of src/matrix.c:881-930
+    cross terms on the pattern of src/matrix.c:881-930 (the K13/K23 terms of the Redi tensor) and, by default
+    (isop_k33), the matching vertical term K33 = K11 s^2 that the model carries in its implicit vertical mixing --
+    without it the tensor (K11, K13; K13, 0) is indefinite, i.e. anti-diffusive across the neutral surface, which no
+    ocean model produces; isop_k33=False gives that round-1 recipe back
   * vmix: vdc/(0.5(dz_k+dz_k+-1))/dz_k*dt (src/matrix.c:2979-2988) with a mixed layer
   * sink const_shallow: -year_cnt*rate where z_t < depth (src/matrix.c:3085-3091)
   * duplicates summed, exact zeros stripped, rows sorted by column (src/matrix.c:3826-3832)
@@ -144,7 +147,7 @@ _SLOTS_ISOP = [(1, 0, -1), (1, 0, 1), (-1, 0, -1), (-1, 0, 1), (0, 1, -1), (0, 1
 
 def generate(imt=12, jmt=10, km=6, seed=0, adv="centred", hmix="const", coupled_tracer_cnt=1,
              day_cnt=365.0, u_scale=3.0, noise=0.3, ah=4.0e6, vdc_bg=0.1, vdc_ml=1000.0,
-             sink_rate=365.0, sink_depth=10.0e2, min_cos=0.3):
+             sink_rate=365.0, sink_depth=10.0e2, min_cos=0.3, isop_k33=True):
     """Build a SynthProblem.  adv in {none, donor, centred, upwind3}; hmix in {const, isop}."""
     rng = np.random.default_rng(seed + 1000)
     dz = pop_like_dz(km)
@@ -271,6 +274,15 @@ def generate(imt=12, jmt=10, km=6, seed=0, adv="centred", hmix="const", coupled_
             V[S[(d[0], d[1], 1)]] -= x
             V[S[(0, 0, -1)]] += x
             V[S[(0, 0, 1)]] -= x
+        if isop_k33:
+            # vertical part K33 = K11 s^2 of the Redi tensor: without it the (K11, K13) terms above form an indefinite
+            # tensor (anti-diffusive across the neutral surface); the model carries K33 in its implicit vertical mixing
+            kz = 0.5 * (ce * sx ** 2 + cw * _shift(sx, -1, 0, 0) ** 2 + cn * sy ** 2 + cs * _shift(sy, 0, -1, 0) ** 2)
+            k33_top = 0.5 * (kz + _shift(kz, 0, 0, -1)) * UP
+            k33_bot = _shift(0.5 * (kz + _shift(kz, 0, 0, -1)), 0, 0, 1) * DN
+            V[0] -= k33_top + k33_bot
+            V[S[(0, 0, -1)]] += k33_top
+            V[S[(0, 0, 1)]] += k33_bot
 
     # ------------------------------------------------------------------ vertical mixing
     mld = (3000.0 + 27000.0 * np.abs(np.sin(np.deg2rad(lat))) ** 3)[None, :, None]   # cm
@@ -358,7 +370,7 @@ def generate(imt=12, jmt=10, km=6, seed=0, adv="centred", hmix="const", coupled_
                         rowptr.astype(np.int32), colind, nzval,
                         meta=dict(seed=seed, adv=adv, hmix=hmix, day_cnt=day_cnt, u_scale=u_scale, noise=noise,
                                   ah=ah, vdc_bg=vdc_bg, vdc_ml=vdc_ml, sink_rate=sink_rate, sink_depth=sink_depth,
-                                  min_cos=min_cos))
+                                  min_cos=min_cos, isop_k33=isop_k33))
 
 
 def write_matrix_file(p: SynthProblem, path, version=2):

@@ -27,7 +27,7 @@ from nk_ocn_tracer_jacobian_precond_amd import synth  # noqa: E402
 CASES = {
     # name: (generator kwargs, tracer variable names)
     "tri_12x10x6": (dict(imt=12, jmt=10, km=6, adv="donor", hmix="const", seed=0), ["IAGE"]),
-    "penta_12x10x6": (dict(imt=12, jmt=10, km=6, adv="upwind3", hmix="isop", seed=0), ["IAGE", "TRACER2"]),
+    "penta_12x10x6": (dict(imt=12, jmt=10, km=6, adv="upwind3", hmix="isop", seed=0, isop_k33=False), ["IAGE", "TRACER2"]),
     "cent_10x9x5": (dict(imt=10, jmt=9, km=5, adv="centred", hmix="const", seed=2), ["IAGE"]),
     "pair_8x8x5": (dict(imt=8, jmt=8, km=5, adv="donor", hmix="const", coupled_tracer_cnt=2, seed=3),
                    ["OCMIP_BGC_PO4", "OCMIP_BGC_DOP"]),
