@@ -1,0 +1,61 @@
+"""BASELINE.json configs[3] and configs[4] and the resolution regime behind them, through the C ABI on one MI355X.
+
+The residual every assertion uses is recomputed by the CPU oracle's SpMV, not taken from the solver's own report."""
+import numpy as np
+import pytest
+
+import oracle_binding as ora
+from nk_ocn_tracer_jacobian_precond_amd import solver, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(p, cnt=1, **kw):
+    blk = solver.column_blocks(p.col_start(), p.tracer_state_len, cnt)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), cnt)
+    b = np.random.default_rng(5).standard_normal(p.flat_len)
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, coupled_tracer_cnt=cnt, **kw) as s:
+        x, info = s.solve(b, raise_on_fail=False)
+        info["levels"] = s.get_int("levels")
+    res = b - ora.spmv(p.rowptr, p.colind, p.nzval, x)
+    info["true_relres"] = float(np.linalg.norm(res) / np.linalg.norm(b))
+    return info
+
+
+@pytest.mark.parametrize("refine", [1.0, 4.0, 12.0])
+def test_cell_courant_number_of_finer_grids(refine):
+    """The 3 degree x 60 grid with the cell-level coefficients of a grid `refine` times finer (velocities x refine,
+    lateral diffusivity x refine^2: cell Courant and diffusion numbers of 3, 0.75 and 0.25 degree).  Round 1 stalled
+    here (the aggregates mixed unconnected water); the iteration count must now stay flat."""
+    p = synth.generate(imt=100, jmt=116, km=60, adv="upwind3", hmix="isop", seed=0, u_scale=3.0 * refine, ah=4.0e6 * refine ** 2)
+    info = _solve(p)
+    assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
+    assert info["iters"] <= 90, info
+
+
+def test_cell_courant_number_round1_recipe():
+    """Same regime with the round-1 synthetic recipe (isopycnal cross terms without the K33 term: an indefinite mixing
+    tensor).  It did not converge at all in round 1 (stall at 7e-3 after 20 000 iterations with block-Jacobi, 0.2-0.3
+    with the multilevel cycle at 0.25 degree); with connectivity-aware aggregates it does, slowly."""
+    p = synth.generate(imt=100, jmt=116, km=60, adv="upwind3", hmix="isop", seed=0, u_scale=36.0, ah=4.0e6 * 144, isop_k33=False)
+    info = _solve(p, max_iters=6000)
+    assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
+
+
+def test_config_4tracer_1deg():
+    """configs[3]: 1 degree x 60 levels x 4 coupled tracers (n = 16.9 M, nnz = 344 M) on one GPU."""
+    p = synth.generate(imt=320, jmt=384, km=60, adv="upwind3", hmix="isop", seed=0, coupled_tracer_cnt=4)
+    assert p.flat_len == 4 * p.tracer_state_len and p.flat_len > 16_000_000
+    info = _solve(p, cnt=4, restart=100)
+    assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
+    assert info["iters"] <= 250, info
+
+
+def test_config_quarter_degree():
+    """configs[4]: 0.25 degree x 80 levels (1440 x 720 x 80, n = 50.7 M, nnz = 893 M) on one GPU -- the system that did
+    not converge in round 1."""
+    p = synth.generate(imt=1440, jmt=720, km=80, adv="upwind3", hmix="isop", seed=0)
+    assert p.flat_len > 50_000_000
+    info = _solve(p, restart=60)
+    assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
+    assert info["iters"] <= 400, info

@@ -29,7 +29,7 @@ ap.add_argument("--ml-smooth", type=int, default=3)
 ap.add_argument("--ml-levels", type=int, default=0)
 ap.add_argument("--min-cos", type=float, default=0.3)
 ap.add_argument("--refine", type=float, default=1.0, help="cell-level coefficients of a grid this many times finer (u x F, ah x F^2)")
-ap.add_argument("--k33", type=int, default=0, help="isop: include the K33 vertical term of the Redi tensor")
+ap.add_argument("--k33", type=int, default=1, help="isop: include the K33 vertical term of the Redi tensor")
 ap.add_argument("--precond-steps", type=int, default=0)
 a = ap.parse_args()
 imt, jmt, km = (int(t) for t in a.grid.split("x"))
