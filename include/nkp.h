@@ -55,6 +55,9 @@ enum {
    NKP_OK = 0,
    NKP_NOT_CONVERGED = 1,    /* max_iters reached; x holds the best iterate, NOT written by the CLIs */
    NKP_BREAKDOWN = 2,
+   NKP_OK_BERR = 3,          /* ||b-Ax||/||b|| stopped above rtol at the attainable f64 accuracy, but the componentwise
+                                backward error is <= max (1e-14, rtol/100); x is written; callers decide (the CLIs accept it
+                                only with NKP_ACCEPT_BERR=1 in the environment) */
    NKP_EINVAL = -1,
    NKP_ENOMEM = -2,
    NKP_EDEVICE = -3,         /* HIP runtime failure / no gfx950 device */
@@ -80,8 +83,12 @@ typedef struct nkp_options {
                             the f64 Z vectors, the true residual is recomputed in f64 at every restart).  Default 0:
                             with a single Gram-Schmidt pass the f32 basis can double the iteration count. */
    int precond_steps;    /* preconditioner cycles per Krylov iteration, chained by defect correction against A:
-                            z = M r; z += M (r - A z); ...  0 = automatic (multilevel: 2 from 2 M rows, 3 from 6 M; else 1) */
-   int reserved[5];
+                            z = M r; z += M (r - A z); ...  0 = automatic (= 1 since round 2) */
+   int equil;            /* row equilibration (SuperLU's Equil=YES, reference src/solve_ABglobal.c:332): FGMRES minimises
+                            ||R (b - A x)||_2 with R = diag (1 / max_j |a_ij|) instead of ||b - A x||_2; the stopping test
+                            stays on the unscaled residual.  0 = automatic (off unless NKP_EQUIL=1), 1 = on, -1 = off.
+                            Column scaling has no effect on a right-preconditioned iteration and is not applied. */
+   int reserved[4];
    /* multilevel, optional: grid position (i, j) of every water-column block, nblk entries each
     * (tracer_state_ind_to_i/_j at the block's first row, reference src/matrix.c:322-329).  With
     * them columns are aggregated 2 x 2 in (i, j) and coloured (i + j) % 2; without them
@@ -109,10 +116,11 @@ int nkp_create (nkp_solver **out, const nkp_options *opt, int64_t n, int64_t nnz
  * when the return code is NKP_OK or NKP_NOT_CONVERGED.  berr[r] receives the componentwise
  * backward error max_i |b-Ax|_i / (|A||x|+|b|)_i like SuperLU's; iters/relres per rhs.
  * Any of berr/iters/relres may be NULL.
- * Converged (NKP_OK) means ||b-Ax||/||b|| <= rtol (or <= atol absolute), or -- when rounding stops the
- * residual from falling further -- a componentwise backward error <= max (1e-14, rtol / 100), which is
- * the accuracy measure the reference itself reports (berr, src/solve_ABglobal.c:396-398).  A solve that stalls above
- * both returns NKP_NOT_CONVERGED after a few restart cycles instead of running to max_iters. */
+ * NKP_OK means ||b-Ax||/||b|| <= rtol (or <= atol absolute) on the true residual, nothing else.  When rounding
+ * stops the residual above rtol (badly scaled rows: even a direct solve with refinement then stays above it) the solve
+ * ends after a few restart cycles instead of running to max_iters and returns NKP_OK_BERR if the componentwise
+ * backward error -- the accuracy measure the reference itself reports (berr, src/solve_ABglobal.c:396-398) -- is
+ * <= max (1e-14, rtol / 100), else NKP_NOT_CONVERGED. */
 int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t ldb,
                double *berr, int *iters, double *relres);
 

@@ -183,6 +183,20 @@ static void options_from_env (nkp_options *o)
    }
 }
 
+// NKP_OK_BERR: the residual stopped above the tolerance at the attainable f64 accuracy while the componentwise backward
+// error -- the only accuracy figure the reference prints (src/solve_ABglobal.c:396-398) -- is at rounding level.  The
+// reference would write such a result without looking; this program writes it only when the caller opts in.
+static int berr_verdict (int info, double relres, double berr)
+{
+   if (info != NKP_OK_BERR) return info;
+   const char *e = getenv ("NKP_ACCEPT_BERR");
+   if (e && atoi (e) != 0) {
+      printf ("(%d) residual %.3e above the tolerance at the attainable accuracy, backward error %.3e: accepted (NKP_ACCEPT_BERR)\n", iam, relres, berr);
+      return 0;
+   }
+   return info;
+}
+
 int main (int argc, char *argv[])
 {
    dbg_lvl = 0;
@@ -412,9 +426,10 @@ int main (int argc, char *argv[])
       for (std::thread &t : workers) t.join ();
       for (size_t w = 1; w < handles.size (); w++) nkp_destroy (handles[w]);
       for (size_t g = 0; g < ng; g++) {
-         const result &r = res[g];
+         result &r = res[g];
          if (dbg_lvl)
             printf ("(%d) nkp_solve info = %d, iterations = %d, relres = %.3e, berr = %.3e\n", iam, r.info, r.iters, r.relres, r.berr);
+         r.info = berr_verdict (r.info, r.relres, r.berr);
          if (r.info) {
             fprintf (stderr, "(%d) nkp_solve failed (info = %d): %s\n(%d) %s left untouched in %s\n", iam, r.info, r.err.c_str (), iam,
                      groups[g][0], inout_fname);
@@ -451,6 +466,7 @@ int main (int argc, char *argv[])
          info = nkp_solve (solver, B + fst_row, 1, m_loc, &berr, &iters, &relres);
          if (dbg_lvl)
             printf ("(%d) nkp_solve info = %d, iterations = %d, relres = %.3e, berr = %.3e\n", iam, info, iters, relres, berr);
+         info = berr_verdict (info, relres, berr);
          if (info) {
             fprintf (stderr, "(%d) nkp_solve failed (info = %d): %s\n(%d) %s left untouched in %s\n", iam, info, nkp_last_error (), iam,
                      vars_per_solve[0], inout_fname);

@@ -217,6 +217,18 @@ void launch_axpby (double a, const double *x, double b, double *y, int64_t n, hi
    hipLaunchKernelGGL (axpby_kernel, dim3 (red_grid (n) * 2), dim3 (B1_THREADS), 0, st, a, x, b, y, n);
 }
 
+__global__ __launch_bounds__ (B1_THREADS)
+void vmul_kernel (const double *x, const double *__restrict__ w, double *y, int64_t n)
+{
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS;
+   for (int64_t i = (int64_t) blockIdx.x * B1_THREADS + threadIdx.x; i < n; i += stride) y[i] = x[i] * w[i];
+}
+
+void launch_vmul (const double *x, const double *w, double *y, int64_t n, hipStream_t st)
+{
+   hipLaunchKernelGGL (vmul_kernel, dim3 (red_grid (n) * 2), dim3 (B1_THREADS), 0, st, x, w, y, n);
+}
+
 void launch_copy (const double *x, double *y, int64_t n, hipStream_t st)
 {
    (void) hipMemcpyAsync (y, x, (size_t) n * sizeof (double), hipMemcpyDeviceToDevice, st);

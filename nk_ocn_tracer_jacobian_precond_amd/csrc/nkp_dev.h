@@ -109,6 +109,8 @@ void launch_finish_column (double *h, const double *h2, int k, const double *nrm
 // y = a*x + b*y style helpers for BiCGStab
 void launch_axpby (double a, const double *x, double b, double *y, int64_t n, hipStream_t st);
 void launch_copy (const double *x, double *y, int64_t n, hipStream_t st);
+// y[i] = x[i] * w[i]   (y may alias x)
+void launch_vmul (const double *x, const double *w, double *y, int64_t n, hipStream_t st);
 void launch_fill (double *y, double v, int64_t n, hipStream_t st);
 
 // ---------------------------------------------------------------- grid transfer / permutation

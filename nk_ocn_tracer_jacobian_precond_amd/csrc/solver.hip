@@ -67,6 +67,7 @@ extern "C" int nkp_default_options (nkp_options *opt)
    opt->ml_levels = 0;
    opt->ml_smooth = 3;
    opt->precond_steps = 0;   // automatic
+   opt->equil = 0;           // automatic
    opt->basis_f32 = 0;       // f32 basis: -11 % time at 1 degree, but it doubled the iterations of the 3 degree solve with one Gram-Schmidt pass
    return NKP_OK;
 }
@@ -101,8 +102,12 @@ struct nkp_solver {
    double *vcur = nullptr;         // f64 copy of the newest basis vector (input of the next preconditioner call)
    double *V = nullptr, *Z = nullptr, *w = nullptr, *r = nullptr, *x = nullptr, *b = nullptr, *t1 = nullptr, *t2 = nullptr;
    double *p1 = nullptr, *p2 = nullptr;   // scratch of the multi-step preconditioner (NKP_PRECOND_STEPS > 1)
-   int precond_steps = 1;
-   bool steps_auto = false;      // precond_steps was chosen here, not by the caller: probe it before the first solve
+   int precond_steps = 1;        // configured cycles per application
+   int steps_now = 1;            // cycles per application of the running solve (the run-time guard may lower it for one solve)
+   bool equil = false;           // row-weighted FGMRES
+   double *rscale = nullptr, *rinv = nullptr;   // R and R^-1 (device), R_i = 1 / max_j |a_ij|
+   double *eqtmp = nullptr;      // R^-1 v_j, the input of the preconditioner in the row-weighted iteration
+   bool comm_failed = false;     // a collective callback returned non-zero: every verdict after that is NKP_ECOMM
    double *partial = nullptr;       // reduction scratch
    double *dscal = nullptr;         // device scalars: h[m+2] | h2[m+2] | misc[16] | ycoef[m+1]
    double *hpin = nullptr;          // pinned host mirror
@@ -130,7 +135,7 @@ static void solver_free (nkp_solver *s)
 {
    if (!s) return;
    if (s->borrowed) {           // a clone owns its work vectors, its level vectors and its stream, nothing else
-      void *own[] = { s->V, s->vcur, s->Z, s->w, s->r, s->x, s->b, s->t1, s->t2, s->p1, s->p2, s->partial, s->dscal, s->dint };
+      void *own[] = { s->V, s->vcur, s->Z, s->w, s->r, s->x, s->b, s->t1, s->t2, s->p1, s->p2, s->eqtmp, s->partial, s->dscal, s->dint };
       for (void *p : own)
          if (p) (void) hipFree (p);
       for (MlLevel &L : s->ml.lev) {
@@ -144,7 +149,7 @@ static void solver_free (nkp_solver *s)
       return;
    }
    void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.grp_row0, s->B.col_slot, s->B.fac_t, s->V, s->vcur, s->Z, s->w, s->r,
-                    s->x, s->b, s->t1, s->t2, s->p1, s->p2, s->partial, s->dscal, s->dint };
+                    s->x, s->b, s->t1, s->t2, s->p1, s->p2, s->partial, s->dscal, s->dint, s->rscale, s->rinv, s->eqtmp };
    for (void *p : ptrs)
       if (p) (void) hipFree (p);
    ml_free (s->ml);
@@ -183,7 +188,7 @@ static void spmv_op (nkp_solver *s, const double *x, double *y, const double *b,
 static void apply_precond (nkp_solver *s, const double *rin, double *zout)
 {
    apply_precond_once (s, rin, zout);
-   for (int k = 1; k < s->precond_steps && s->p1 && s->p2; k++) {
+   for (int k = 1; k < s->steps_now && s->p1 && s->p2; k++) {
       spmv_op (s, zout, s->p1, rin, 1);
       apply_precond_once (s, s->p1, s->p2);
       launch_axpby (1.0, s->p2, 1.0, zout, s->n, s->stream);
@@ -198,8 +203,9 @@ static void spmv_op (nkp_solver *s, const double *x, double *y, const double *b,
    if (s->dist.on) {
       launch_copy (x, s->dist.xe, s->n, s->stream);
       if (s->dist.nsend) launch_gather (s->dist.send_idx, x, s->dist.sendbuf, s->dist.nsend, s->stream);
-      (void) s->dist.ops.alltoallv (s->dist.ops.ctx, s->dist.sendbuf, s->dist.send_counts.data (), s->dist.xe + s->n,
-                                    s->dist.recv_counts.data (), (void *) s->stream);
+      if (s->dist.ops.alltoallv (s->dist.ops.ctx, s->dist.sendbuf, s->dist.send_counts.data (), s->dist.xe + s->n,
+                                 s->dist.recv_counts.data (), (void *) s->stream))
+         s->comm_failed = true;      // stale halo rows: checked before any verdict is returned
       xin = s->dist.xe;
    }
    if (mode == 2) launch_csr_abs_spmv (s->A, xin, b, y, s->stream);
@@ -208,7 +214,7 @@ static void spmv_op (nkp_solver *s, const double *x, double *y, const double *b,
 
 static inline void allreduce_dev (nkp_solver *s, double *dev, int count, int op)
 {
-   if (s->dist.on) (void) s->dist.ops.allreduce (s->dist.ops.ctx, dev, count, op, (void *) s->stream);
+   if (s->dist.on && s->dist.ops.allreduce (s->dist.ops.ctx, dev, count, op, (void *) s->stream)) s->comm_failed = true;
 }
 
 // the SpMV matrix (device copy; columns may address halo slots >= n) and the matrix the preconditioner
@@ -293,13 +299,18 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    s->ld = (n + 63) & ~(int64_t) 63;
    if (s->ld == 0) s->ld = 64;
    s->m = opt.restart;
-   // cycles per preconditioner application (defect correction against A between them): measured 1 degree 772 its /
-   // 3.17 s with one, 410 / 2.93 s with two, 307 / 3.02 s with three; 0.5 degree 3190 / 24.8 s, 1373 / 17.7 s, 805 / 14.5 s
-   // small systems are latency-bound and gain nothing (3 degree: 160 instead of 250 iterations but 0.38 s instead of 0.33 s)
-   s->precond_steps = (opt.precond == NKP_PRECOND_MULTILEVEL) ? (n >= 6000000 ? 3 : n >= 2000000 ? 2 : 1) : 1;
-   s->steps_auto = s->precond_steps > 1;
-   if (opt.precond_steps > 0) { s->precond_steps = opt.precond_steps; s->steps_auto = false; }
-   { const char *e = getenv ("NKP_PRECOND_STEPS"); if (e && atoi (e) > 0) { s->precond_steps = atoi (e); s->steps_auto = false; } }
+   // cycles per preconditioner application (defect correction against A between them).  Round 1 chained 2-3 cycles
+   // on large systems because every Krylov iteration dragged a 200-vector basis through HBM; with the connectivity-aware
+   // aggregates a 1 degree solve needs 78 iterations with one cycle (0.29 s) against 48 with two (0.33 s), 0.25 degree
+   // 167 / 6.8 s against 89 / 6.7 s, so one cycle is the automatic choice everywhere (and no rank-dependent choice
+   // can desynchronise the collectives of the distributed flavour); the option stays
+   s->precond_steps = 1;
+   if (opt.precond_steps > 0) s->precond_steps = opt.precond_steps;
+   { const char *e = getenv ("NKP_PRECOND_STEPS"); if (e && atoi (e) > 0) s->precond_steps = atoi (e); }
+   s->steps_now = s->precond_steps;
+   s->equil = opt.equil > 0;
+   { const char *e = getenv ("NKP_EQUIL"); if (e && opt.equil == 0) s->equil = atoi (e) != 0; }
+   if (opt.krylov != NKP_KRYLOV_FGMRES) s->equil = false;
 
    // matrix
    const SpmvMatrixHost own = { nnz, n, rowptr, colind, val };
@@ -326,6 +337,20 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
       if (rc != NKP_OK) { solver_free (s); return rc; }
    }
 
+   if (s->equil) {
+      // R_i = 1 / max_j |a_ij| (the row half of dgsequ); rows without entries keep 1
+      std::vector<double> rs ((size_t) n, 1.0), ri ((size_t) n, 1.0);
+      for (int64_t r = 0; r < n; r++) {
+         double mx = 0.0;
+         for (int e = M.rowptr[r]; e < M.rowptr[r + 1]; e++) mx = fmax (mx, fabs (M.val[e]));
+         if (mx > 0.0) { rs[(size_t) r] = 1.0 / mx; ri[(size_t) r] = mx; }
+      }
+      TRY (dev_alloc (s, &s->rscale, (size_t) s->ld));
+      TRY (dev_alloc (s, &s->rinv, (size_t) s->ld));
+      TRYHIP (hipMemcpy (s->rscale, rs.data (), (size_t) n * sizeof (double), hipMemcpyHostToDevice));
+      TRYHIP (hipMemcpy (s->rinv, ri.data (), (size_t) n * sizeof (double), hipMemcpyHostToDevice));
+   }
+
    // work space
    const int m = s->m;
    TRY (dev_alloc (s, &s->V, (size_t) s->ld * (size_t) (m + 1)));
@@ -342,6 +367,7 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
       TRY (dev_alloc (s, &s->p1, (size_t) s->ld));
       TRY (dev_alloc (s, &s->p2, (size_t) s->ld));
    }
+   if (s->equil) TRY (dev_alloc (s, &s->eqtmp, (size_t) s->ld));
    TRY (dev_alloc (s, &s->partial, (size_t) ((m + 1 + NKP_DOT_CHUNK) / NKP_DOT_CHUNK + 1) * NKP_RED_BLOCKS * (NKP_DOT_CHUNK + 1)));
    TRY (dev_alloc (s, &s->dscal, (size_t) (3 * (m + 2) + 16 + 8)));
    TRY (dev_alloc (s, &s->dint, 8));
@@ -462,6 +488,7 @@ extern "C" int64_t nkp_get_int (nkp_solver *s, const char *key)
    if (!strcmp (key, "precond_bytes")) return s->opt.precond == NKP_PRECOND_NONE ? 16 * s->n : (int64_t) (2 * s->B.P + 1) * 8 * s->n + 16 * s->n;
    if (!strcmp (key, "device_bytes")) return (int64_t) s->device_bytes;
    if (!strcmp (key, "precond_steps")) return s->precond_steps;
+   if (!strcmp (key, "equil")) return s->equil ? 1 : 0;
    return -1;
 }
 
@@ -483,8 +510,16 @@ static void arnoldi_step_device (nkp_solver *s, int j)
    const int64_t ld = s->ld;
    double *zj = s->Z + (int64_t) j * ld;
    const double *vj = s->vf32 ? s->vcur : s->V + (int64_t) j * ld;
-   apply_precond (s, vj, zj);
-   spmv_op (s, zj, s->w, nullptr, 0);
+   if (s->equil) {
+      // row-weighted iteration: the basis lives in the scaled space, operator R A M R^-1
+      launch_vmul (vj, s->rinv, s->eqtmp, s->n, s->stream);
+      apply_precond (s, s->eqtmp, zj);
+      spmv_op (s, zj, s->w, nullptr, 0);
+      launch_vmul (s->w, s->rscale, s->w, s->n, s->stream);
+   } else {
+      apply_precond (s, vj, zj);
+      spmv_op (s, zj, s->w, nullptr, 0);
+   }
    launch_multi_dot (s->V, s->vf32, ld, j + 1, s->w, s->n, s->partial, s->h_dev (), s->stream);
    allreduce_dev (s, s->h_dev (), j + 2, 0);                 // one allreduce per Gram-Schmidt pass
    launch_update_w (s->V, s->vf32, ld, j + 1, s->h_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
@@ -531,34 +566,46 @@ static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
    double beta_prev = 0.0, est_at_exit = 0.0, inner_scale = 1.0;
    int stalled_cycles = 0;
    s->stagnated = false;
+   s->steps_now = s->precond_steps;      // the run-time guard below lowers it for this solve only
    for (;;) {
-      // true residual
+      // true residual (unscaled: the stopping test is ||b - A x||_2 <= rtol ||b||_2 whatever norm the iteration minimises)
       spmv_op (s, s->x, s->r, s->b, 1);
       double r2 = 0.0;
       if ((rc = dot_host (s, s->r, s->r, &r2))) return rc;
       const double beta = sqrt (r2);
       relres = beta / bnorm;
       msg (s, 2, "fgmres: its = %d, true relres = %.3e\n", its, relres);
+      if (s->comm_failed) return fail (NKP_ECOMM, "nkp_solve: a collective of the distributed solve failed");
       if (!(beta == beta)) { status = NKP_BREAKDOWN; break; }
       if (beta <= target) { status = NKP_OK; break; }
       if (its >= s->opt.max_iters) { status = NKP_NOT_CONVERGED; break; }
-      if (s->precond_steps > 1 && its > 0 && !(beta < beta_prev)) {
-         // a whole restart cycle without progress: the chained cycles are not helping on this matrix
-         msg (s, 1, "fgmres: no progress over a restart cycle with %d preconditioner cycles per iteration; continuing with one\n", s->precond_steps);
-         s->precond_steps = 1;
+      if (s->steps_now > 1 && its > 0 && !(beta < beta_prev)) {
+         // a whole restart cycle without progress: the chained cycles are not helping on this right-hand side
+         msg (s, 1, "fgmres: no progress over a restart cycle with %d preconditioner cycles per iteration; continuing with one\n", s->steps_now);
+         s->steps_now = 1;
       }
       stalled_cycles = (cycle_ended_on_estimate && beta > 0.7 * beta_prev) ? stalled_cycles + 1 : 0;
       if (stalled_cycles >= 3) { status = NKP_NOT_CONVERGED; s->stagnated = true; break; }
       if (cycle_ended_on_estimate && est_at_exit > 0.0) inner_scale = fmax (1e-3, fmin (inner_scale, 0.5 * est_at_exit / beta));
       beta_prev = beta;
       cycle_ended_on_estimate = false;
-      // v0 = r / beta
-      s->hpin[0] = 1.0 / beta;
+      // v0 = r / beta; in the row-weighted iteration v0 = R r / ||R r|| and the inner target is the same relative
+      // reduction in that norm (the inner_scale logic above corrects it from what the next true residual shows)
+      double beta_it = beta, target_it = target;
+      if (s->equil) {
+         launch_vmul (s->r, s->rscale, s->r, n, st);
+         double q2 = 0.0;
+         if ((rc = dot_host (s, s->r, s->r, &q2))) return rc;
+         beta_it = sqrt (q2);
+         if (!(beta_it > 0.0)) { status = NKP_BREAKDOWN; break; }
+         target_it = target * (beta_it / beta);
+      }
+      s->hpin[0] = 1.0 / beta_it;
       HIPCHK (hipMemcpyAsync (s->misc_dev () + 1, s->hpin, sizeof (double), hipMemcpyHostToDevice, st));
       if (s->vf32) launch_scale_to (s->r, s->misc_dev () + 1, s->vcur, (float *) s->V, n, st);
       else launch_scale_to (s->r, s->misc_dev () + 1, s->V, nullptr, n, st);
       HIPCHK (hipStreamSynchronize (st));      // hpin is reused below
-      g[0] = beta;
+      g[0] = beta_it;
       int j = 0;
       for (; j < m && its < s->opt.max_iters; j++) {
          arnoldi_step_device (s, j);
@@ -583,7 +630,7 @@ static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
          its++;
          const double est = fabs (g[j + 1]);
          msg (s, 3, "fgmres: its = %d, est relres = %.3e\n", its, est / bnorm);
-         if (est <= target * inner_scale || hj1 == 0.0) { j++; cycle_ended_on_estimate = true; est_at_exit = est; break; }
+         if (est <= target_it * inner_scale || hj1 == 0.0) { j++; cycle_ended_on_estimate = true; est_at_exit = est * (beta / beta_it); break; }
       }
       // y = H^-1 g (upper triangular, size j), x += Z y
       const int k = j;
@@ -694,59 +741,11 @@ static int backward_error (nkp_solver *s, double *berr)
    return NKP_OK;
 }
 
-// Chaining cycles by defect correction, z += M (r - A z), repeats the stationary iteration with E = I - M A.  Inside
-// FGMRES it pays even when E expands mildly (0.5 degree: growth 1.30 per step, yet 805 iterations / 14.5 s with three
-// cycles against 3190 / 24.8 s with one), but a strongly expanding E makes the chained operator so ill-conditioned
-// that rounding wins (seen on a badly scaled coupled-tracer matrix).  Eight steps of the power method from a fixed
-// pseudo-random start (25 ms at 1 degree) estimate the growth from below; at 1.6 or more the solver stays with one
-// cycle per iteration.  fgmres() has a run-time guard for what this estimate misses.
-static int probe_defect_correction (nkp_solver *s)
-{
-   s->steps_auto = false;
-   if (s->precond_steps <= 1) return NKP_OK;
-   if (s->m < 2 || s->n == 0) { s->precond_steps = 1; return NKP_OK; }
-   double *v = s->Z, *av = s->Z + s->ld, *z = s->w;
-   {
-      std::vector<double> h ((size_t) s->n);
-      uint64_t state = 0x9E3779B97F4A7C15ull + (uint64_t) (s->dist.on ? s->dist.fst : 0);
-      for (int64_t i = 0; i < s->n; i++) {
-         state = state * 6364136223846793005ull + 1442695040888963407ull;
-         h[(size_t) i] = (double) (int64_t) (state >> 11) / 9007199254740992.0 - 0.5;
-      }
-      HIPCHK (hipMemcpyAsync (v, h.data (), (size_t) s->n * sizeof (double), hipMemcpyHostToDevice, s->stream));
-      HIPCHK (hipStreamSynchronize (s->stream));
-   }
-   int rc;
-   double nrm2 = 0.0, rho = 0.0;
-   if ((rc = dot_host (s, v, v, &nrm2))) return rc;
-   launch_axpby (0.0, v, 1.0 / sqrt (nrm2), v, s->n, s->stream);
-   for (int it = 0; it < 8; it++) {
-      spmv_op (s, v, av, nullptr, 0);
-      apply_precond_once (s, av, z);
-      launch_axpby (-1.0, z, 1.0, v, s->n, s->stream);
-      if ((rc = dot_host (s, v, v, &nrm2))) return rc;
-      const double growth = sqrt (nrm2);
-      if (it >= 5) rho = fmax (rho, growth);
-      if (!(growth > 0.0) || !(growth == growth)) { rho = (growth == 0.0) ? rho : 2.0; break; }
-      launch_axpby (0.0, v, 1.0 / growth, v, s->n, s->stream);
-   }
-   if (!(rho < 1.6)) {
-      msg (s, 1, "defect-correction probe: |I - M A| grows by %.3f per step; one preconditioner cycle per iteration\n", rho);
-      s->precond_steps = 1;
-   } else
-      msg (s, 1, "defect-correction probe: |I - M A| changes by %.3f per step; %d preconditioner cycles per iteration\n", rho, s->precond_steps);
-   return NKP_OK;
-}
-
 static int solve_resident (nkp_solver *s, double *berr, int *iters, double *relres)
 {
    int it = 0;
    double rr = 0.0;
    s->stagnated = false;
-   if (s->steps_auto) {
-      int prc = probe_defect_correction (s);
-      if (prc) return prc;
-   }
    int status = (s->opt.krylov == NKP_KRYLOV_BICGSTAB) ? bicgstab (s, &it, &rr) : fgmres (s, &it, &rr);
    if (status < 0) return status;
    double be = 0.0;
@@ -758,14 +757,16 @@ static int solve_resident (nkp_solver *s, double *berr, int *iters, double *relr
    // the reference's only accuracy measure is SuperLU's componentwise backward error: a solve that has reached
    // the attainable accuracy with berr at rounding level, or two orders below the requested tolerance (berr bounds
    // the normwise backward error), is as converged as f64 allows, whatever ||r||/||b|| is
+   if (s->comm_failed) return fail (NKP_ECOMM, "nkp_solve: a collective of the distributed solve failed");
    if (status == NKP_NOT_CONVERGED && s->stagnated && be <= fmax (NKP_BERR_ROUNDING_LEVEL, 1.0e-2 * s->opt.rtol)) {
-      msg (s, 1, "nkp_solve: residual stagnated at %.3e with backward error %.3e: accepted\n", rr, be);
-      status = NKP_OK;
+      msg (s, 1, "nkp_solve: residual stagnated at %.3e (rtol %.1e) with backward error %.3e: NKP_OK_BERR\n", rr, s->opt.rtol, be);
+      status = NKP_OK_BERR;
    }
    if (iters) *iters = it;
    if (relres) *relres = rr;
-   msg (s, 1, "nkp_solve: %s after %d iterations, ||b-Ax||/||b|| = %.3e\n", status == NKP_OK ? "converged" : status == NKP_BREAKDOWN ? "breakdown" : "NOT converged", it, rr);
-   if (status != NKP_OK) fail (status, "nkp_solve: %s after %d iterations (relres %.3e, rtol %.1e)", status == NKP_BREAKDOWN ? "breakdown" : s->stagnated ? "stagnated at the attainable accuracy, not converged" : "not converged", it, rr, s->opt.rtol);
+   msg (s, 1, "nkp_solve: %s after %d iterations, ||b-Ax||/||b|| = %.3e\n", status == NKP_OK ? "converged" : status == NKP_OK_BERR ? "at the attainable accuracy (backward error accepted)" : status == NKP_BREAKDOWN ? "breakdown" : "NOT converged", it, rr);
+   if (status == NKP_OK_BERR) fail (status, "nkp_solve: ||b-Ax||/||b|| = %.3e stopped above rtol %.1e at the attainable accuracy after %d iterations; componentwise backward error %.3e", rr, s->opt.rtol, it, be);
+   else if (status != NKP_OK) fail (status, "nkp_solve: %s after %d iterations (relres %.3e, rtol %.1e)", status == NKP_BREAKDOWN ? "breakdown" : s->stagnated ? "stagnated at the attainable accuracy, not converged" : "not converged", it, rr, s->opt.rtol);
    return status;
 }
 
@@ -801,7 +802,7 @@ extern "C" int nkp_clone (nkp_solver *src, nkp_solver **out)
    s->stream = nullptr;
    s->own_stream = false;
    s->device_bytes = 0;
-   s->V = s->vcur = s->Z = s->w = s->r = s->x = s->b = s->t1 = s->t2 = s->p1 = s->p2 = s->partial = s->dscal = s->hpin = nullptr;
+   s->V = s->vcur = s->Z = s->w = s->r = s->x = s->b = s->t1 = s->t2 = s->p1 = s->p2 = s->eqtmp = s->partial = s->dscal = s->hpin = nullptr;
    s->dint = nullptr;
    for (MlLevel &L : s->ml.lev) L.x = L.b = L.r = nullptr;
    int rc = NKP_OK;
@@ -823,6 +824,7 @@ extern "C" int nkp_clone (nkp_solver *src, nkp_solver **out)
       TRY (dev_alloc (s, &s->p1, (size_t) s->ld));
       TRY (dev_alloc (s, &s->p2, (size_t) s->ld));
    }
+   if (s->equil) TRY (dev_alloc (s, &s->eqtmp, (size_t) s->ld));
    TRY (dev_alloc (s, &s->partial, (size_t) ((m + 1 + NKP_DOT_CHUNK) / NKP_DOT_CHUNK + 1) * NKP_RED_BLOCKS * (NKP_DOT_CHUNK + 1)));
    TRY (dev_alloc (s, &s->dscal, (size_t) (3 * (m + 2) + 16 + 8)));
    TRY (dev_alloc (s, &s->dint, 8));
@@ -857,7 +859,9 @@ extern "C" int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t l
       if (status < 0) return status;
       HIPCHK (hipMemcpyAsync (col, s->x, bytes, hipMemcpyDeviceToHost, s->stream));
       HIPCHK (hipStreamSynchronize (s->stream));
-      if (status > worst) worst = status;
+      // severity: OK < OK_BERR < NOT_CONVERGED < BREAKDOWN
+      auto sev = [] (int c) { return c == NKP_OK ? 0 : c == NKP_OK_BERR ? 1 : c == NKP_NOT_CONVERGED ? 2 : 3; };
+      if (sev (status) > sev (worst)) worst = status;
    }
    return worst;
 }

@@ -18,7 +18,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "host", "libnkp_host.so")
 
 PRECOND_NONE, PRECOND_COLUMN_JACOBI, PRECOND_MULTILEVEL = 0, 1, 3
 KRYLOV_FGMRES, KRYLOV_BICGSTAB = 0, 1
-NKP_OK, NKP_NOT_CONVERGED, NKP_BREAKDOWN = 0, 1, 2
+NKP_OK, NKP_NOT_CONVERGED, NKP_BREAKDOWN, NKP_OK_BERR = 0, 1, 2, 3
 
 # every symbol include/nkp.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -46,7 +46,7 @@ class NkpOptions(C.Structure):
         ("struct_size", C.c_int), ("precond", C.c_int), ("krylov", C.c_int), ("restart", C.c_int),
         ("max_iters", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("device", C.c_int),
         ("verbose", C.c_int), ("rank", C.c_int), ("reorth", C.c_int), ("ml_levels", C.c_int),
-        ("ml_smooth", C.c_int), ("basis_f32", C.c_int), ("precond_steps", C.c_int), ("reserved", C.c_int * 5),
+        ("ml_smooth", C.c_int), ("basis_f32", C.c_int), ("precond_steps", C.c_int), ("equil", C.c_int), ("reserved", C.c_int * 4),
         ("col_i", C.POINTER(C.c_int32)), ("col_j", C.POINTER(C.c_int32)),
     ]
 
@@ -200,7 +200,7 @@ class NkpSolver:
             raise ValueError(f"b has {x.size} entries, expected {self.n}")
         berr, relres, iters = C.c_double(), C.c_double(), C.c_int()
         rc = self._lib.nkp_solve(self._h, _p(x, C.c_double), 1, self.n, C.byref(berr), C.byref(iters), C.byref(relres))
-        self._check(rc, (0,) if raise_on_fail else (0, 1, 2))
+        self._check(rc, (0,) if raise_on_fail else (0, 1, 2, 3))
         return x, dict(status=rc, iters=iters.value, relres=relres.value, berr=berr.value)
 
     def solve_device(self, d_b, d_x, use_guess=False, raise_on_fail=True):
@@ -208,7 +208,7 @@ class NkpSolver:
         berr, relres, iters = C.c_double(), C.c_double(), C.c_int()
         rc = self._lib.nkp_solve_device(self._h, C.c_void_p(d_b), C.c_void_p(d_x), int(use_guess), C.byref(berr),
                                         C.byref(iters), C.byref(relres))
-        self._check(rc, (0,) if raise_on_fail else (0, 1, 2))
+        self._check(rc, (0,) if raise_on_fail else (0, 1, 2, 3))
         return dict(status=rc, iters=iters.value, relres=relres.value, berr=berr.value)
 
     def spmv(self, x):
