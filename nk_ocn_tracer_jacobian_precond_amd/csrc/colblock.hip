@@ -435,9 +435,10 @@ static int up (T **dst, const std::vector<T> &src, size_t *bytes)
 }
 
 int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const int *ranges, int nranges,
-                                int *grp_first, size_t *device_bytes, hipStream_t st, int f32)
+                                int *grp_first, size_t *device_bytes, hipStream_t st, int f32, const int *h_rowptr)
 {
-   std::vector<int> b0, nb, ml, row0, nrow, cslot, clen;
+   std::vector<int> b0, nb, ml, row0, nrow, cslot, clen, rb_ptr, rb_bd;
+   bool gs_ok = h_rowptr != nullptr;
    std::vector<long long> base;
    // columns per wave: the group's factors + right-hand side must fit LDS several times per CU
    int gw = 8;
@@ -469,9 +470,28 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
          ml.push_back (m);
          base.push_back (total);
          total += (long long) ndiag * m * gw;
+         if (gs_ok) {
+            // row blocks of the fused sweep kernel: consecutive rows of the group, <= GS_NNZ entries and <= GS_THREADS rows each
+            rb_ptr.push_back ((int) rb_bd.size ());
+            int r = h_blk_start[b];
+            const int rend = h_blk_start[b + cnt];
+            while (r < rend) {
+               int r2 = r + 1;
+               if (h_rowptr[r2] - h_rowptr[r] > GS_NNZ) { gs_ok = false; break; }
+               while (r2 < rend && r2 - r < GS_THREADS && h_rowptr[r2 + 1] - h_rowptr[r] <= GS_NNZ) r2++;
+               rb_bd.push_back (r);
+               r = r2;
+            }
+         }
       }
    }
    grp_first[nranges] = (int) b0.size ();
+   if (gs_ok) {
+      rb_ptr.push_back ((int) rb_bd.size ());
+      rb_bd.push_back (ranges[nranges] > 0 ? h_blk_start[ranges[nranges]] : 0);
+      int rc2;
+      if ((rc2 = up (&B.gs_rb_ptr, rb_ptr, device_bytes)) || (rc2 = up (&B.gs_rb, rb_bd, device_bytes))) return rc2;
+   }
    B.ngrp = (int) b0.size ();
    lds_need = (lds_need + 1) & ~1;                 // keep the factor area 16-byte aligned
    B.rhs_slots = lds_need;
@@ -494,6 +514,12 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    if (B.ngrp)
       hipLaunchKernelGGL (colblock_transpose_kernel, dim3 (B.ngrp), dim3 (NKP_WAVE), 0, st, B.blk_start, B.grp_b0, B.grp_nb, B.grp_maxlen,
                           B.grp_base, ndiag, B.n, B.fac, B.fac_t, gw, B.fac_tf);
+   if (gs_ok) {
+      const int gs_bytes = (GS_NNZ + lds_need) * (int) sizeof (double);
+      if (gs_bytes > 64 * 1024) gs_ok = false;          // not worth running one workgroup per CU
+      B.gs_lds_bytes = gs_bytes;
+   }
+   B.gs_ok = gs_ok ? 1 : 0;
    // dynamic LDS above the default limit needs an explicit opt-in
    const int lds_bytes = lds_need * (int) sizeof (double);
    if (lds_bytes > 160 * 1024) return (int) hipErrorInvalidValue;
@@ -629,6 +655,178 @@ void colblock_apply_lanes_pipe_kernel (const int *__restrict__ grp_nb, const int
       g = gn;
    }
 #undef LANES_PREFETCH
+}
+
+
+// ================================================================ fused Gauss-Seidel half sweep
+// One launch per colour instead of two (residual SpMV over the colour's rows, then the column solves): a workgroup owns
+// one group of <= gw consecutive water columns, computes r = b - L x for the group's rows block by block in the SpMV's
+// CSR-stream fashion (coalesced (value, column) streams, x gathered through L2, products parked in LDS, one lane per row
+// sums its segment) straight into LDS, then lanes 0..nb-1 of its first wave run the band substitutions on the LDS image,
+// and the group's rows of x are written once.  r never goes to HBM, the factor block is requested before the first row
+// block so its latency hides under the SpMV phase, and half of the cycle's launches disappear (the small levels sit at
+// their launch-latency floor).
+// x comes from TWO buffers: rows < split (colour 0) from xa, the rest from xb, and the new values of this colour go to
+// xout -- the columns of one colour are coupled to each other (upwind3's +-2 neighbours, stub columns), so updating x in
+// place would make the result depend on which workgroup ran first.  The caller ping-pongs the buffers (multilevel.hip).
+// Same products, same per-row summation order, same substitution order as the two-kernel path => identical bits.
+template <int P, class FT, class VT>
+__global__ __launch_bounds__ (GS_THREADS)
+void gs_fused_kernel (const int *__restrict__ rowptr, const int *__restrict__ colind, const VT *__restrict__ val,
+                      const int *__restrict__ grp_nb, const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
+                      const FT *__restrict__ fac_t, int gw, int rhs_slots, const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp,
+                      const int *__restrict__ gs_rb_ptr, const int *__restrict__ gs_rb,
+                      const double *__restrict__ xa, const double *__restrict__ xb, int split, const double *__restrict__ b, double *__restrict__ xout)
+{
+   extern __shared__ double lds[];            // prod[GS_NNZ] | rs[rhs_slots] | the group's factors
+   double *prod = lds;
+   double *rs = lds + GS_NNZ;
+   FT *fl = reinterpret_cast<FT *> (rs + rhs_slots);
+   const int g = blockIdx.x + g_first;
+   const int tid = threadIdx.x;
+   const int nb = grp_nb[g], ml = grp_maxlen[g];
+   const int R0 = grp_row0[g], nrows = grp_row0[ngrp + g];
+   const int rb0 = gs_rb_ptr[g], rb1 = gs_rb_ptr[g + 1];
+   int s_pre = 0, len_pre = 0;
+   if (tid < gw) { s_pre = col_slot[g * gw + tid]; len_pre = col_slot[(ngrp + g) * gw + tid]; }
+   // the factor block: requested now, parked in registers, committed to LDS after the SpMV phase
+   constexpr int FB = 4;                       // 16-byte loads per thread and batch
+   const double2 *fsrc = reinterpret_cast<const double2 *> (fac_t + grp_base[g]);
+   double2 *fdst = reinterpret_cast<double2 *> (fl);
+   const int cnt2 = (int) (((size_t) (2 * P + 1) * ml * gw * sizeof (FT)) >> 4);
+   double2 ft0[FB];
+#pragma unroll
+   for (int u = 0; u < FB; u++) {
+      const int i = tid + u * GS_THREADS;
+      ft0[u] = (i < cnt2) ? fsrc[i] : make_double2 (0.0, 0.0);
+   }
+   // residual of the group's rows, row block by row block
+   for (int rb = rb0; rb < rb1; rb++) {
+      const int r0 = gs_rb[rb], r1 = gs_rb[rb + 1];
+      const int e0 = rowptr[r0], e1 = rowptr[r1];
+      const int cnt = e1 - e0;
+      int seg0 = 0, seg1 = 0;
+      double bv = 0.0;
+      if (r0 + tid < r1) { seg0 = rowptr[r0 + tid]; seg1 = rowptr[r0 + tid + 1]; bv = b[r0 + tid]; }
+#pragma unroll 4
+      for (int k = tid; k < cnt; k += GS_THREADS) {
+         const int c = colind[e0 + k];
+         const double xv = (c < split) ? xa[c] : xb[c];
+         prod[k] = (double) val[e0 + k] * xv;
+      }
+      __syncthreads ();
+      if (r0 + tid < r1) {
+         double acc = 0.0;
+         const int s0 = seg0 - e0, s1 = seg1 - e0;
+#pragma unroll 4
+         for (int k = s0; k < s1; k++) acc += prod[k];
+         rs[LDS_PAD (r0 + tid - R0)] = bv - acc;
+      }
+      __syncthreads ();
+   }
+   // factors into LDS (first batch from the registers, any rest straight through)
+#pragma unroll
+   for (int u = 0; u < FB; u++) {
+      const int i = tid + u * GS_THREADS;
+      if (i < cnt2) fdst[i] = ft0[u];
+   }
+   for (int i = tid + FB * GS_THREADS; i < cnt2; i += GS_THREADS) fdst[i] = fsrc[i];
+   __syncthreads ();
+
+   if (tid < nb) {
+      const int s = s_pre, len = len_pre;
+      const FT *ft = fl + tid;
+      const int dstride = ml * gw;
+      // forward: y_k = ((r_k - l(k,k-P) y_{k-P}) ... - l(k,k-1) y_{k-1}), 8 steps per LDS round trip
+      double carry[P];
+#pragma unroll
+      for (int q = 0; q < P; q++) carry[q] = 0.0;            // carry[q-1] = y_{k0-q}
+      for (int k0 = 0; k0 < ml; k0 += 8) {
+         double t[8];
+#pragma unroll
+         for (int j = 0; j < 8; j++) t[j] = (k0 + j < len) ? rs[LDS_PAD (s + k0 + j)] : 0.0;
+#pragma unroll
+         for (int j = 0; j < 8; j++) {
+            const int k = k0 + j;
+            double y = t[j];
+#pragma unroll
+            for (int q = P; q >= 1; q--) {
+               const double prev = (j - q >= 0) ? t[j - q >= 0 ? j - q : 0] : carry[q - j - 1 >= 0 && q - j - 1 < P ? q - j - 1 : 0];
+               if (k - q >= 0) y -= (double) ft[(P - q) * dstride + k * gw] * prev;
+            }
+            t[j] = y;
+         }
+#pragma unroll
+         for (int j = 0; j < 8; j++)
+            if (k0 + j < len) rs[LDS_PAD (s + k0 + j)] = t[j];
+#pragma unroll
+         for (int q = 1; q <= P; q++) carry[q - 1] = t[8 - q];
+      }
+      // backward: x_k = (((y_k - u(k,k+P) x_{k+P}) ... - u(k,k+1) x_{k+1}) * (1/u_kk)
+      double nxt[P];
+#pragma unroll
+      for (int q = 0; q < P; q++) nxt[q] = 0.0;              // nxt[q] = x_{k0+8+q}
+      for (int k0 = ml - 8; k0 >= 0; k0 -= 8) {
+         double t[8];
+#pragma unroll
+         for (int j = 0; j < 8; j++) t[j] = (k0 + j < len) ? rs[LDS_PAD (s + k0 + j)] : 0.0;
+#pragma unroll
+         for (int j = 7; j >= 0; j--) {
+            const int k = k0 + j;
+            double x = t[j];
+#pragma unroll
+            for (int q = P; q >= 1; q--) {
+               const double nv = (j + q <= 7) ? t[j + q <= 7 ? j + q : 7] : nxt[j + q - 8 >= 0 && j + q - 8 < P ? j + q - 8 : 0];
+               if (k + q < ml) x -= (double) ft[(P + q) * dstride + k * gw] * nv;
+            }
+            x *= (double) ft[P * dstride + k * gw];
+            t[j] = x;
+         }
+#pragma unroll
+         for (int j = 0; j < 8; j++)
+            if (k0 + j < len) rs[LDS_PAD (s + k0 + j)] = t[j];
+#pragma unroll
+         for (int q = 0; q < P; q++) nxt[q] = t[q];
+      }
+   }
+   __syncthreads ();
+   for (int i = tid; i < nrows; i += GS_THREADS) {
+      const int row = R0 + i;
+      const double xo = (row < split) ? xa[row] : xb[row];
+      xout[row] = xo + rs[LDS_PAD (i)];
+   }
+}
+
+int launch_gs_fused (const CsrDev &L, const ColBlocksDev &B, int g0, int g1, const double *xa, const double *xb, int split, const double *b, double *xout, hipStream_t st)
+{
+   if (!B.gs_ok) return 1;
+   if (g1 <= g0) return 0;
+   static bool opted = false;
+   if (!opted) {
+      opted = true;
+#define GS_OPT_IN(PP)                                                                                                                    \
+      (void) hipFuncSetAttribute ((const void *) gs_fused_kernel<PP, float, float>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);   \
+      (void) hipFuncSetAttribute ((const void *) gs_fused_kernel<PP, double, double>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
+      GS_OPT_IN (1); GS_OPT_IN (2); GS_OPT_IN (4);
+#undef GS_OPT_IN
+   }
+#define GS_LAUNCH(PP)                                                                                                                                       \
+   do {                                                                                                                                                     \
+      if (B.fac_tf && L.valf)                                                                                                                               \
+         hipLaunchKernelGGL ((gs_fused_kernel<PP, float, float>), dim3 (g1 - g0), dim3 (GS_THREADS), (size_t) B.gs_lds_bytes, st, L.rowptr, L.colind, L.valf, \
+                             B.grp_nb, B.grp_maxlen, B.grp_base, g0, B.fac_tf, B.gw, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp, B.gs_rb_ptr, B.gs_rb,         \
+                             xa, xb, split, b, xout);                                                                                                        \
+      else if (B.fac_t && !L.valf)                                                                                                                          \
+         hipLaunchKernelGGL ((gs_fused_kernel<PP, double, double>), dim3 (g1 - g0), dim3 (GS_THREADS), (size_t) B.gs_lds_bytes, st, L.rowptr, L.colind, L.val, \
+                             B.grp_nb, B.grp_maxlen, B.grp_base, g0, B.fac_t, B.gw, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp, B.gs_rb_ptr, B.gs_rb,           \
+                             xa, xb, split, b, xout);                                                                                                        \
+      else return 1;                                                                                                                                        \
+   } while (0)
+   if (B.P == 1) GS_LAUNCH (1);
+   else if (B.P == 2) GS_LAUNCH (2);
+   else GS_LAUNCH (4);
+#undef GS_LAUNCH
+   return 0;
 }
 
 void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const double *r, double *z, int accumulate, hipStream_t st)

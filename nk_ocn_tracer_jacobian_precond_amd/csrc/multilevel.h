@@ -11,10 +11,17 @@ struct MlLevel {
    int color_rb[3] = { 0, 0, 0 };    // SpMV row blocks of colour c: [color_rb[c], color_rb[c+1])
    int color_blk[3] = { 0, 0, 0 };   // column blocks of colour c
    int color_grp[3] = { 0, 0, 0 };   // lane-per-column groups of colour c
+   int64_t rows0 = 0;           // rows of colour 0 (they come first)
    int64_t nc = 0;              // rows of the next coarser level
    int *cmap = nullptr;         // fine row -> coarse row                 (prolongation)
    int *rptr = nullptr, *ridx = nullptr;   // coarse row -> its fine rows (restriction)
    double *x = nullptr, *b = nullptr, *r = nullptr;
+   // fused half sweeps ping-pong between x and x2: xs[k] is buffer k, cur[c] the buffer that holds the current values
+   // of colour c's rows; the level's x is coherent (one buffer) whenever cur[0] == cur[1]
+   double *x2 = nullptr;
+   int cur[2] = { 0, 0 };
+   double *xbuf (int k) { return k ? x2 : x; }
+   double *xnow () { return xbuf (cur[0]); }      // valid when coherent
 };
 
 struct MlHierarchy {
@@ -25,6 +32,7 @@ struct MlHierarchy {
    int nu_coarse = 1;           // ... on levels >= coarse_from
    int coarse_from = 2;
    int f32 = 1;                 // store level operators / factors in f32 (arithmetic stays f64)
+   int fused = 1;               // one launch per Gauss-Seidel half sweep (gs_fused_kernel) where the level allows it
    int gamma_from = 0, gamma_to = 0;   // levels [from, to) apply the coarse-grid correction twice (W-cycle there)
    double omega = 0.0;          // scaling of the coarse-grid correction (0 = not read yet; NKP_ML_OMEGA, default 1)
    size_t device_bytes = 0;

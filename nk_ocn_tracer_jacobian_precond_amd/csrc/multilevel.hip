@@ -690,6 +690,12 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
    H.nu = nu < 1 ? 1 : nu;
    H.f32 = 1;                                     // level operators and factors stored in f32, arithmetic in f64
    if (const char *e = getenv ("NKP_ML_F32")) H.f32 = atoi (e) != 0;
+   // one launch per half sweep (gs_fused_kernel): bit-identical, but measured slower than the two tuned kernels -- 1 degree
+   // cycle 3.62 against 2.65 ms, 3 degree 1.56 against 1.26 ms: a workgroup walks its group's 2-3 row blocks one after the
+   // other, each exposing the stream -> gather -> row-sum latency chain that the standalone SpMV hides with one block per
+   // workgroup and hundreds of workgroups in flight -- so it stays off (NKP_ML_FUSED=1 turns it on)
+   H.fused = 0;
+   if (const char *e = getenv ("NKP_ML_FUSED")) H.fused = atoi (e) != 0;
    H.nu_coarse = H.nu;
    if (const char *e = getenv ("NKP_ML_SMOOTH_COARSE")) { const int v = atoi (e); if (v >= 1) H.nu_coarse = v; }
    if (const char *e = getenv ("NKP_ML_COARSE_FROM")) { const int v = atoi (e); if (v >= 1) H.coarse_from = v; }
@@ -740,6 +746,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       V.color_blk[1] = N.ncol0;
       V.color_blk[2] = ncol;
       const int rows0 = pblk[N.ncol0];
+      V.rows0 = rows0;
       // row blocks per colour (must not straddle the colour boundary)
       int *rb0 = nullptr, *rb1 = nullptr, nrb0 = 0, nrb1 = 0;
       build_rowblocks_host (rows0, prow.data (), &rb0, &nrb0);
@@ -766,6 +773,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
                 upload_padded (&V.L.val, pval.data (), (size_t) prow[nl], 2, &H.device_bytes) &&
                 upload (&V.L.rowblk, rb.data (), rb.size (), &H.device_bytes) &&
                 upload (&V.x, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
+                upload (&V.x2, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
                 upload (&V.b, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
                 upload (&V.r, (const double *) nullptr, (size_t) nl, &H.device_bytes);
       if (ok) ok = attach_spmv_codes (V.L, prow.data (), pcol.data (), rb.data (), &H.device_bytes) == 0;
@@ -803,7 +811,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          V.B.dropped = st2[1];
          {
             const int ranges[3] = { 0, N.ncol0, ncol };
-            const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st, H.f32);
+            const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st, H.f32, H.fused ? prow.data () : nullptr);
             if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
          }
          // transfer operators in permuted orders
@@ -848,7 +856,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 void ml_free (MlHierarchy &H)
 {
    for (MlLevel &V : H.lev) {
-      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.valf, V.B.fac_tf, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.grp_row0, V.B.col_slot, V.B.fac_t, V.cmap, V.rptr, V.ridx, V.x, V.b, V.r };
+      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.valf, V.B.fac_tf, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.grp_row0, V.B.col_slot, V.B.fac_t, V.B.gs_rb_ptr, V.B.gs_rb, V.cmap, V.rptr, V.ridx, V.x, V.x2, V.b, V.r };
       for (void *p : ptrs)
          if (p) (void) hipFree (p);
    }
@@ -860,13 +868,25 @@ void ml_free (MlHierarchy &H)
 }
 
 // ================================================================ cycle
-static void gs_sweep (MlLevel &V, bool reverse, hipStream_t st)
+// one Gauss-Seidel half sweep over colour c.  Fused path: one launch, x ping-pongs between the level's two buffers (the
+// new values of colour c go where the other colour's current values are if the level is incoherent, else to the other
+// buffer).  Two-kernel path: residual SpMV of the colour's rows, then the column solves accumulate into x in place.
+static void gs_half (MlLevel &V, int c, bool fused, hipStream_t st)
 {
-   for (int step = 0; step < 2; step++) {
-      const int c = reverse ? 1 - step : step;
-      launch_csr_residual_range (V.L, V.color_rb[c], V.color_rb[c + 1], V.x, V.b, V.r, st);
-      launch_colblock_apply_lanes (V.B, V.color_grp[c], V.color_grp[c + 1], V.r, V.x, 1, st);
+   if (fused) {
+      const int out = (V.cur[0] != V.cur[1]) ? V.cur[1 - c] : 1 - V.cur[c];
+      const int rows0 = (int) V.rows0;
+      launch_gs_fused (V.L, V.B, V.color_grp[c], V.color_grp[c + 1], V.xbuf (V.cur[0]), V.xbuf (V.cur[1]), rows0, V.b, V.xbuf (out), st);
+      V.cur[c] = out;
+      return;
    }
+   launch_csr_residual_range (V.L, V.color_rb[c], V.color_rb[c + 1], V.x, V.b, V.r, st);
+   launch_colblock_apply_lanes (V.B, V.color_grp[c], V.color_grp[c + 1], V.r, V.x, 1, st);
+}
+
+static void gs_sweep (MlLevel &V, bool reverse, bool fused, hipStream_t st)
+{
+   for (int step = 0; step < 2; step++) gs_half (V, reverse ? 1 - step : step, fused, st);
 }
 
 static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
@@ -878,28 +898,37 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
       if ((e = getenv ("NKP_ML_GAMMA_TO"))) H.gamma_to = atoi (e);
    }
    MlLevel &V = H.lev[l];
+   V.cur[0] = V.cur[1] = 0;
    if (l == (int) H.lev.size () - 1) {
       launch_dense_matvec (H.coarse_inv, V.b, V.x, (int) V.n, st);
       return;
    }
+   const bool fused = H.fused && V.B.gs_ok;
    // pre-smoothing from x = 0: the first half-sweep needs no SpMV (r = b on colour 0)
    launch_fill (V.x, 0.0, V.n, st);
-   launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.b, V.x, 0, st);
-   launch_csr_residual_range (V.L, V.color_rb[1], V.color_rb[2], V.x, V.b, V.r, st);
-   launch_colblock_apply_lanes (V.B, V.color_grp[1], V.color_grp[2], V.r, V.x, 1, st);
+   if (fused) {
+      // colour 0's first values go to the second buffer: the level starts incoherent, and the odd number of fused half
+      // sweeps that follows (colour 1, then nu - 1 full sweeps) ends coherent
+      launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.b, V.x2, 0, st);
+      V.cur[0] = 1;
+      gs_half (V, 1, true, st);
+   } else {
+      launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.b, V.x, 0, st);
+      gs_half (V, 1, false, st);
+   }
    const int nu = (l >= H.coarse_from) ? H.nu_coarse : H.nu;
-   for (int s = 1; s < nu; s++) gs_sweep (V, false, st);
+   for (int s = 1; s < nu; s++) gs_sweep (V, false, fused, st);
    // coarse-grid correction; levels in [gamma_from, gamma_to) repeat it on the updated residual, which by the
    // Galerkin property is the second coarse iteration of a W-cycle (NKP_ML_GAMMA_FROM / NKP_ML_GAMMA_TO, default off)
    MlLevel &C = H.lev[l + 1];
    const int gamma = (l >= H.gamma_from && l < H.gamma_to) ? 2 : 1;
    for (int g = 0; g < gamma; g++) {
-      launch_csr_spmv (V.L, V.x, V.r, V.b, 1, st);
+      launch_csr_spmv (V.L, V.xnow (), V.r, V.b, 1, st);
       launch_restrict_sum (V.rptr, V.ridx, V.r, C.b, V.nc, st);
       ml_cycle (H, l + 1, st);
-      launch_prolong_add (V.cmap, C.x, V.x, V.n, H.omega, st);
+      launch_prolong_add (V.cmap, C.xnow (), V.xnow (), V.n, H.omega, st);
    }
-   for (int s = 0; s < nu; s++) gs_sweep (V, true, st);
+   for (int s = 0; s < nu; s++) gs_sweep (V, true, fused, st);
 }
 
 void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st)
@@ -907,5 +936,5 @@ void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st)
    MlLevel &V = H.lev[0];
    launch_gather (H.perm0, r, V.b, V.n, st);
    ml_cycle (H, 0, st);
-   launch_scatter (H.perm0, V.x, z, V.n, st);
+   launch_scatter (H.perm0, V.xnow (), z, V.n, st);
 }

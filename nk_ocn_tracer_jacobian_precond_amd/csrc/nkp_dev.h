@@ -67,13 +67,26 @@ struct ColBlocksDev {
    int lds_doubles = 0;        // LDS staging need of the largest group (padded)
    int gw = 64;                // columns (lanes in use) per group
    int rhs_slots = 0;          // LDS doubles reserved for the staged right-hand side
+   // fused Gauss-Seidel half sweep (gs_fused_kernel): row blocks of every group's rows
+   int gs_ok = 0;              // 1 if the level can run it (no row longer than GS_NNZ, LDS need within 64 KB)
+   int gs_lds_bytes = 0;
+   int *gs_rb_ptr = nullptr;   // [ngrp+1] first row-block boundary of the group
+   int *gs_rb = nullptr;       // row-block boundaries (rows), groups back to back
 };
+
+#define GS_THREADS 256
+#define GS_NNZ 2048
 
 // Build the lane-per-column layout.  ranges: nranges+1 block offsets; a group never straddles a
 // range boundary (Gauss-Seidel colours).  grp_first[r] = first group of range r (nranges+1 out).
 // Returns 0 or a HIP error code cast to int.
 int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const int *ranges, int nranges,
-                                int *grp_first, size_t *device_bytes, hipStream_t st, int f32 = 0);
+                                int *grp_first, size_t *device_bytes, hipStream_t st, int f32 = 0, const int *h_rowptr = nullptr);
+// one Gauss-Seidel half sweep over the groups [g0, g1) of one colour in ONE launch: r = b - L x on the groups' rows
+// (x rows < split from xa, the others from xb), column solves, xout_rows = x_rows + z.  Returns non-zero (and does
+// nothing) when the level cannot run the fused kernel.
+int launch_gs_fused (const CsrDev &L, const ColBlocksDev &B, int g0, int g1, const double *xa, const double *xb, int split,
+                     const double *b, double *xout, hipStream_t st);
 // groups [g0, g1): z (+)= M^-1 r, one water column per LANE, rhs staged through LDS
 void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const double *r, double *z, int accumulate, hipStream_t st);
 

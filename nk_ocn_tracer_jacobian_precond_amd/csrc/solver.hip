@@ -139,7 +139,7 @@ static void solver_free (nkp_solver *s)
       for (void *p : own)
          if (p) (void) hipFree (p);
       for (MlLevel &L : s->ml.lev) {
-         void *lv[] = { L.x, L.b, L.r };
+         void *lv[] = { L.x, L.x2, L.b, L.r };
          for (void *p : lv)
             if (p) (void) hipFree (p);
       }
@@ -148,7 +148,7 @@ static void solver_free (nkp_solver *s)
       delete s;
       return;
    }
-   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.grp_row0, s->B.col_slot, s->B.fac_t, s->V, s->vcur, s->Z, s->w, s->r,
+   void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.grp_row0, s->B.col_slot, s->B.fac_t, s->B.gs_rb_ptr, s->B.gs_rb, s->V, s->vcur, s->Z, s->w, s->r,
                     s->x, s->b, s->t1, s->t2, s->p1, s->p2, s->partial, s->dscal, s->dint, s->rscale, s->rinv, s->eqtmp };
    for (void *p : ptrs)
       if (p) (void) hipFree (p);
@@ -804,7 +804,7 @@ extern "C" int nkp_clone (nkp_solver *src, nkp_solver **out)
    s->device_bytes = 0;
    s->V = s->vcur = s->Z = s->w = s->r = s->x = s->b = s->t1 = s->t2 = s->p1 = s->p2 = s->eqtmp = s->partial = s->dscal = s->hpin = nullptr;
    s->dint = nullptr;
-   for (MlLevel &L : s->ml.lev) L.x = L.b = L.r = nullptr;
+   for (MlLevel &L : s->ml.lev) L.x = L.x2 = L.b = L.r = nullptr;
    int rc = NKP_OK;
 #define TRY(x) do { rc = (x); if (rc != NKP_OK) { solver_free (s); return rc; } } while (0)
 #define TRYHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = fail (NKP_EDEVICE, "%s failed: %s", #call, hipGetErrorString (e_)); solver_free (s); return rc; } } while (0)
@@ -832,9 +832,11 @@ extern "C" int nkp_clone (nkp_solver *src, nkp_solver **out)
    TRYHIP (hipMemset (s->dscal, 0, (size_t) (3 * (m + 2) + 16 + 8) * sizeof (double)));
    for (MlLevel &L : s->ml.lev) {
       TRY (dev_alloc (s, &L.x, (size_t) L.n));
+      TRY (dev_alloc (s, &L.x2, (size_t) L.n));
       TRY (dev_alloc (s, &L.b, (size_t) L.n));
       TRY (dev_alloc (s, &L.r, (size_t) L.n));
       TRYHIP (hipMemset (L.x, 0, (size_t) (L.n ? L.n : 1) * sizeof (double)));
+      TRYHIP (hipMemset (L.x2, 0, (size_t) (L.n ? L.n : 1) * sizeof (double)));
       TRYHIP (hipMemset (L.b, 0, (size_t) (L.n ? L.n : 1) * sizeof (double)));
       TRYHIP (hipMemset (L.r, 0, (size_t) (L.n ? L.n : 1) * sizeof (double)));
    }

@@ -574,3 +574,32 @@ def test_row_equilibration_option(medium, golden_by_name):
         x, info = s.solve(g.rhs(g.groups()[0]))
     xg = g.gold["x_" + g.groups()[0]]
     assert info["relres"] <= 1e-12 and np.linalg.norm(x - xg) / np.linalg.norm(xg) <= 1e-7
+
+
+@pytest.mark.parametrize("case", ["medium", "tracers2", "dense_blocks"])
+def test_fused_half_sweeps_are_bit_identical(case, medium, monkeypatch):
+    """gs_fused_kernel (one launch per Gauss-Seidel half sweep: residual rows + column solves, x ping-ponged between two
+    buffers) against the two-kernel path: same products, same summation and substitution order => the same bits, for
+    f32 and f64 storage of the level operators."""
+    if case == "medium":
+        p, blk = medium
+        cnt = 1
+    elif case == "tracers2":
+        p = synth.generate(imt=40, jmt=46, km=20, adv="upwind3", hmix="isop", coupled_tracer_cnt=2, seed=3)
+        cnt = 2
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, cnt)
+    else:
+        p = synth.generate(imt=24, jmt=20, km=70, adv="centred", hmix="const", seed=5)      # columns longer than one wavefront
+        cnt = 1
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, cnt)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), cnt)
+    r = np.random.default_rng(23).standard_normal(p.flat_len)
+    for f32 in ("1", "0"):
+        monkeypatch.setenv("NKP_ML_F32", f32)
+        z = {}
+        for fused in ("0", "1"):
+            monkeypatch.setenv("NKP_ML_FUSED", fused)
+            with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, coupled_tracer_cnt=cnt, restart=4) as s:
+                z[fused] = s.precond_apply(r)
+        assert np.isfinite(z["1"]).all()
+        assert np.array_equal(z["0"], z["1"]), (case, f32, np.abs(z["0"] - z["1"]).max())
