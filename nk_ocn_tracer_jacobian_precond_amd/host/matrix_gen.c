@@ -13,6 +13,7 @@
  *
  * Units as in the reference: POP cgs, delta_t in seconds, sink rates per year.
  */
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,122 +57,93 @@ static void trace (const char *what, const char *subname)
 }
 
 /* ------------------------------------------------------------------ index maps */
-
-static int comp_tracer_state_len (void)
-{
-   char *subname = "comp_tracer_state_len";
-
-   trace ("entering", subname);
-   if (nkp_check_polar_rows (subname))
-      return 1;
-   tracer_state_len = 0;
-   for (int j = 0; j < jmt; j++)
-      for (int i = 0; i < imt; i++)
-         tracer_state_len += KMT[j][i];
-   if (dbg_lvl)
-      printf ("(%d) tracer_state_len = %d\n\n", iam, tracer_state_len);
-   trace ("exiting", subname);
-   return 0;
-}
-
-/* flat ordering: latitude rows outermost, then longitude, depth innermost -- every water
- * column is one contiguous run (reference src/matrix.c:239-251) */
+/* The flat state vector numbers the ocean cells with latitude rows outermost, then longitude, depth innermost, so
+ * that every water column is one contiguous run (the ordering the reference fixes in src/matrix.c:239-251 and that
+ * both solvers and the preconditioner's column blocks rely on).  Built by a prefix sum over the column depths:
+ * column (j, i) owns the indices [first, first + KMT[j][i]). */
 int gen_ind_maps (void)
 {
-   char *subname = "gen_ind_maps";
-   int tracer_state_ind = 0;
+   const char *who = "gen_ind_maps";
+   long total = 0;
 
-   trace ("entering", subname);
-   if (comp_tracer_state_len ()) {
-      fprintf (stderr, "(%d) comp_tracer_state_len call failed in %s\n", iam, subname);
+   trace ("entering", (char *) who);
+   if (nkp_check_polar_rows ("comp_tracer_state_len")) {
+      fprintf (stderr, "(%d) comp_tracer_state_len call failed in %s\n", iam, who);
       return 1;
    }
-   if ((int3_to_tracer_state_ind = malloc_3d_int (km, jmt, imt)) == NULL) {
-      fprintf (stderr, "(%d) malloc failed in %s for int3_to_tracer_state_ind\n", iam, subname);
-      return 1;
-   }
-   if ((tracer_state_ind_to_int3 = (int3 *) malloc ((size_t) (tracer_state_len ? tracer_state_len : 1) * sizeof (int3))) == NULL) {
-      fprintf (stderr, "(%d) malloc failed in %s for tracer_state_ind_to_int3\n", iam, subname);
-      return 1;
-   }
-   if (dbg_lvl > 2)
-      printf ("(%d) mappings between flat and 3d indices\n", iam);
    for (int j = 0; j < jmt; j++)
-      for (int i = 0; i < imt; i++)
-         for (int k = 0; k < km; k++)
-            if (k < KMT[j][i]) {
-               if (dbg_lvl > 2)
-                  printf ("(%d) i = %3d, j = %3d, k = %2d, tracer_state_ind = %d\n", iam, i, j, k, tracer_state_ind);
-               int3_to_tracer_state_ind[k][j][i] = tracer_state_ind;
-               tracer_state_ind_to_int3[tracer_state_ind].i = i;
-               tracer_state_ind_to_int3[tracer_state_ind].j = j;
-               tracer_state_ind_to_int3[tracer_state_ind].k = k;
-               tracer_state_ind++;
-            } else
-               int3_to_tracer_state_ind[k][j][i] = -1;
-   trace ("exiting", subname);
+      for (int i = 0; i < imt; i++) total += KMT[j][i];
+   tracer_state_len = (int) total;
+   if (dbg_lvl) printf ("(%d) tracer_state_len = %d\n\n", iam, tracer_state_len);
+
+   int3_to_tracer_state_ind = malloc_3d_int (km, jmt, imt);
+   tracer_state_ind_to_int3 = int3_to_tracer_state_ind ? (int3 *) malloc ((size_t) (total ? total : 1) * sizeof (int3)) : NULL;
+   if (tracer_state_ind_to_int3 == NULL) {
+      fprintf (stderr, "(%d) malloc failed in %s for %s\n", iam, who, int3_to_tracer_state_ind ? "tracer_state_ind_to_int3" : "int3_to_tracer_state_ind");
+      return 1;
+   }
+   if (dbg_lvl > 2) printf ("(%d) mappings between flat and 3d indices\n", iam);
+   int first = 0;
+   for (int j = 0; j < jmt; j++)
+      for (int i = 0; i < imt; i++) {
+         const int depth = KMT[j][i];
+         for (int k = 0; k < km; k++) int3_to_tracer_state_ind[k][j][i] = (k < depth) ? first + k : -1;
+         for (int k = 0; k < depth; k++) {
+            tracer_state_ind_to_int3[first + k] = (int3) { .i = i, .j = j, .k = k };
+            if (dbg_lvl > 2) printf ("(%d) i = %3d, j = %3d, k = %2d, tracer_state_ind = %d\n", iam, i, j, k, first + k);
+         }
+         first += depth;
+      }
+   trace ("exiting", (char *) who);
    return 0;
 }
 
+/* the index-map section of the matrix file: the cube (with the -1 land marker declared as fill and missing value) and
+ * the three inverse maps; schema as the reference writes it (src/matrix.c:263-369) */
 int put_ind_maps (char *fname)
 {
-   char *subname = "put_ind_maps";
-   char *ijk_vars[3] = { "tracer_state_ind_to_i", "tracer_state_ind_to_j", "tracer_state_ind_to_k" };
+   char *who = "put_ind_maps";
+   static const char *grid_dims[3] = { "z_t", "nlat", "nlon" };
+   static const struct { const char *var; size_t member; } inverse[3] = {
+      { "tracer_state_ind_to_i", offsetof (int3, i) }, { "tracer_state_ind_to_j", offsetof (int3, j) }, { "tracer_state_ind_to_k", offsetof (int3, k) } };
+   static const char *marker_atts[2] = { "_FillValue", "missing_value" };
+   const int land = -1;
+   int status, cube_dims[3], len_dim, varid;
    nc3_file *f;
-   int status, varid;
-   int dimids[3];
-   int tracer_state_len_dimid;
-   int attval_int = -1;
-   char *string = "TLONG TLAT";
-   int *tmp;
 
-   trace ("entering", subname);
-   if ((status = nc3_open (fname, 1, &f)))
-      return handle_nc_error (subname, "nc_open", fname, status);
-   if ((status = nc3_redef (f)))
-      return handle_nc_error (subname, "nc_redef", fname, status);
-   if ((status = nc3_def_dim (f, "tracer_state_len", (size_t) tracer_state_len, &tracer_state_len_dimid)))
-      return handle_nc_error (subname, "nc_def_dim", "tracer_state_len", status);
-   if ((status = nc3_inq_dimid (f, "nlon", &dimids[2])))
-      return handle_nc_error (subname, "nc_inq_dimid", "nlon", status);
-   if ((status = nc3_inq_dimid (f, "nlat", &dimids[1])))
-      return handle_nc_error (subname, "nc_inq_dimid", "nlat", status);
-   if ((status = nc3_inq_dimid (f, "z_t", &dimids[0])))
-      return handle_nc_error (subname, "nc_inq_dimid", "z_t", status);
-
-   if ((status = nc3_def_var (f, "int3_to_tracer_state_ind", NC3_INT, 3, dimids, &varid)))
-      return handle_nc_error (subname, "nc_def_var", "int3_to_tracer_state_ind", status);
-   if ((status = nc3_put_att_text (f, varid, "coordinates", strlen (string), string)))
-      return handle_nc_error (subname, "nc_put_att_text", "int3_to_tracer_state_ind", status);
-   if ((status = nc3_put_att_int (f, varid, "_FillValue", NC3_INT, 1, &attval_int)))
-      return handle_nc_error (subname, "nc_put_att_int", "int3_to_tracer_state_ind", status);
-   if ((status = nc3_put_att_int (f, varid, "missing_value", NC3_INT, 1, &attval_int)))
-      return handle_nc_error (subname, "nc_put_att_int", "int3_to_tracer_state_ind", status);
-
-   dimids[0] = tracer_state_len_dimid;
+   trace ("entering", who);
+   if ((status = nc3_open (fname, 1, &f))) return handle_nc_error (who, "nc_open", fname, status);
+   if ((status = nc3_redef (f))) return handle_nc_error (who, "nc_redef", fname, status);
+   if ((status = nc3_def_dim (f, "tracer_state_len", (size_t) tracer_state_len, &len_dim)))
+      return handle_nc_error (who, "nc_def_dim", "tracer_state_len", status);
+   for (int d = 0; d < 3; d++)
+      if ((status = nc3_inq_dimid (f, grid_dims[d], &cube_dims[d]))) return handle_nc_error (who, "nc_inq_dimid", (char *) grid_dims[d], status);
+   if ((status = nc3_def_var (f, "int3_to_tracer_state_ind", NC3_INT, 3, cube_dims, &varid)))
+      return handle_nc_error (who, "nc_def_var", "int3_to_tracer_state_ind", status);
+   if ((status = nc3_put_att_text (f, varid, "coordinates", strlen ("TLONG TLAT"), "TLONG TLAT")))
+      return handle_nc_error (who, "nc_put_att_text", "int3_to_tracer_state_ind", status);
+   for (int a = 0; a < 2; a++)
+      if ((status = nc3_put_att_int (f, varid, marker_atts[a], NC3_INT, 1, &land)))
+         return handle_nc_error (who, "nc_put_att_int", "int3_to_tracer_state_ind", status);
    for (int c = 0; c < 3; c++)
-      if ((status = nc3_def_var (f, ijk_vars[c], NC3_INT, 1, dimids, &varid)))
-         return handle_nc_error (subname, "nc_def_var", ijk_vars[c], status);
-   if ((status = nc3_close (f)))
-      return handle_nc_error (subname, "nc_close", fname, status);
+      if ((status = nc3_def_var (f, inverse[c].var, NC3_INT, 1, &len_dim, &varid)))
+         return handle_nc_error (who, "nc_def_var", (char *) inverse[c].var, status);
+   if ((status = nc3_close (f))) return handle_nc_error (who, "nc_close", fname, status);
 
-   if (put_var_3d_int (fname, "int3_to_tracer_state_ind", int3_to_tracer_state_ind))
-      return 1;
-   if ((tmp = (int *) malloc ((size_t) (tracer_state_len ? tracer_state_len : 1) * sizeof (int))) == NULL) {
-      fprintf (stderr, "(%d) malloc failed in %s for tracer_state_ind_to_ijk\n", iam, subname);
+   if (put_var_3d_int (fname, "int3_to_tracer_state_ind", int3_to_tracer_state_ind)) return 1;
+   int *column = (int *) malloc ((size_t) (tracer_state_len ? tracer_state_len : 1) * sizeof (int));
+   if (column == NULL) {
+      fprintf (stderr, "(%d) malloc failed in %s for tracer_state_ind_to_ijk\n", iam, who);
       return 1;
    }
-   for (int c = 0; c < 3; c++) {
-      for (int s = 0; s < tracer_state_len; s++)
-         tmp[s] = (c == 0) ? tracer_state_ind_to_int3[s].i : (c == 1) ? tracer_state_ind_to_int3[s].j : tracer_state_ind_to_int3[s].k;
-      if (put_var_1d_int (fname, ijk_vars[c], tmp)) {
-         free (tmp);
-         return 1;
-      }
+   int failed = 0;
+   for (int c = 0; c < 3 && !failed; c++) {
+      for (int s = 0; s < tracer_state_len; s++) column[s] = *(const int *) ((const char *) &tracer_state_ind_to_int3[s] + inverse[c].member);
+      failed = put_var_1d_int (fname, (char *) inverse[c].var, column);
    }
-   free (tmp);
-   trace ("exiting", subname);
-   return 0;
+   free (column);
+   trace ("exiting", who);
+   return failed ? 1 : 0;
 }
 
 /* ------------------------------------------------------------------ row layout */
@@ -455,124 +427,76 @@ static void for_rows_of_tracer (int t, row_term term, void *arg)
 
 /* ------------------------------------------------------------------ advection, centred / donor */
 
-/* volume transports through the east / north faces of T cells from the B-grid velocities
- * at the cell corners (reference src/matrix.c:986-1207) */
-static double ***load_UTE (void)
-{
-   char *subname = "load_UTE";
-   double ***UTE = zeros_3d ();
-   double ***WORK;
-   double **DY;
+/* Volume transports through the faces of the T cells (what the reference assembles in src/matrix.c:986-1207).
+ * A lateral face is bounded by two velocity points (B grid: velocities sit on the cell corners): its transport is the
+ * mean of the two corner velocities times the corner spacing, each corner counting only where it is ocean (k < KMU);
+ * with hmix_hor_file the eddy-induced (bolus) velocity of the face itself, times the face length, is added where the
+ * cells on both sides are ocean.  One recipe per face orientation says which fields and which neighbours. */
+typedef struct {
+   const char *who;                            /* label of the -D1 progress lines */
+   const char *vel, *corner_len;               /* corner velocity and the grid spacing that multiplies it */
+   int tap_dj, tap_di;                         /* the face's second corner relative to corner (j, i) */
+   const char *bolus, *face_len;               /* bolus velocity and face length (hmix_hor_file only) */
+   int bolus_fill_aware;                       /* 0: the bolus field is read raw, fill values included */
+   int across_dj, across_di;                   /* the T cell on the far side of the face */
+} face_recipe;
 
-   if (UTE == NULL)
-      return NULL;
-   if (dbg_lvl)
-      printf ("(%d) %s: reading UVEL,DYU from %s\n", iam, subname, circ_fname);
-   if ((WORK = read_3d (circ_fname, "UVEL", 1)) == NULL)
-      return NULL;
-   if ((DY = read_2d (circ_fname, "DYU", 1)) == NULL)
-      return NULL;
+static const face_recipe EAST_FACE = { "load_UTE", "UVEL", "DYU", -1, 0, "UISOP", "HTE", 0, 0, 1 };
+static const face_recipe NORTH_FACE = { "load_VTN", "VVEL", "DXU", 0, -1, "VISOP", "HTN", 1, 1, 0 };
+
+static double ***load_face_transport (const face_recipe *F)
+{
+   double ***T = zeros_3d ();
+   double ***vel;
+   double **len;
+
+   if (T == NULL) return NULL;
+   if (dbg_lvl) printf ("(%d) %s: reading %s,%s from %s\n", iam, F->who, F->vel, F->corner_len, circ_fname);
+   if ((vel = read_3d (circ_fname, (char *) F->vel, 1)) == NULL || (len = read_2d (circ_fname, (char *) F->corner_len, 1)) == NULL) return NULL;
    for (int k = 0; k < km; k++)
       for (int j = 1; j < jmt - 1; j++)
          for (int i = 0; i < imt; i++) {
-            if (k < KMU[j][i])
-               UTE[k][j][i] += 0.5 * WORK[k][j][i] * DY[j][i];
-            if (k < KMU[j - 1][i])
-               UTE[k][j][i] += 0.5 * WORK[k][j - 1][i] * DY[j - 1][i];
+            const int cj[2] = { j, j + F->tap_dj }, ci[2] = { i, (i + F->tap_di + imt) % imt };
+            for (int c = 0; c < 2; c++)
+               if (k < KMU[cj[c]][ci[c]]) T[k][j][i] += 0.5 * vel[k][cj[c]][ci[c]] * len[cj[c]][ci[c]];
          }
-   free_2d_double (DY);
-   free_3d_double (WORK);
-   if (hmix_opt == hmix_hor_file) {
-      /* bolus transport; UISOP is read without fill-value treatment in the reference (:1036) */
-      if (dbg_lvl)
-         printf ("(%d) %s: reading UISOP,HTE from %s\n", iam, subname, circ_fname);
-      if ((WORK = read_3d (circ_fname, "UISOP", 0)) == NULL)
-         return NULL;
-      if ((DY = read_2d (circ_fname, "HTE", 1)) == NULL)
-         return NULL;
-      for (int k = 0; k < km; k++)
-         for (int j = 1; j < jmt - 1; j++)
-            for (int i = 0; i < imt; i++) {
-               int ip1 = (i < imt - 1) ? i + 1 : 0;
-               if ((k < KMT[j][i]) && (k < KMT[j][ip1]))
-                  UTE[k][j][i] += WORK[k][j][i] * DY[j][i];
-            }
-      free_2d_double (DY);
-      free_3d_double (WORK);
-   }
-   return UTE;
-}
+   free_2d_double (len);
+   free_3d_double (vel);
+   if (hmix_opt != hmix_hor_file) return T;
 
-static double ***load_VTN (void)
-{
-   char *subname = "load_VTN";
-   double ***VTN = zeros_3d ();
-   double ***WORK;
-   double **DX;
-
-   if (VTN == NULL)
-      return NULL;
-   if (dbg_lvl)
-      printf ("(%d) %s: reading VVEL,DXU from %s\n", iam, subname, circ_fname);
-   if ((WORK = read_3d (circ_fname, "VVEL", 1)) == NULL)
-      return NULL;
-   if ((DX = read_2d (circ_fname, "DXU", 1)) == NULL)
-      return NULL;
+   if (dbg_lvl) printf ("(%d) %s: reading %s,%s from %s\n", iam, F->who, F->bolus, F->face_len, circ_fname);
+   if ((vel = read_3d (circ_fname, (char *) F->bolus, F->bolus_fill_aware)) == NULL || (len = read_2d (circ_fname, (char *) F->face_len, 1)) == NULL) return NULL;
    for (int k = 0; k < km; k++)
       for (int j = 1; j < jmt - 1; j++)
-         for (int i = 0; i < imt; i++) {
-            int im1 = (i > 0) ? i - 1 : imt - 1;
-            if (k < KMU[j][i])
-               VTN[k][j][i] += 0.5 * WORK[k][j][i] * DX[j][i];
-            if (k < KMU[j][im1])
-               VTN[k][j][i] += 0.5 * WORK[k][j][im1] * DX[j][im1];
-         }
-   free_2d_double (DX);
-   free_3d_double (WORK);
-   if (hmix_opt == hmix_hor_file) {
-      if (dbg_lvl)
-         printf ("(%d) %s: reading VISOP,HTN from %s\n", iam, subname, circ_fname);
-      if ((WORK = read_3d (circ_fname, "VISOP", 1)) == NULL)
-         return NULL;
-      if ((DX = read_2d (circ_fname, "HTN", 1)) == NULL)
-         return NULL;
-      for (int k = 0; k < km; k++)
-         for (int j = 1; j < jmt - 1; j++)
-            for (int i = 0; i < imt; i++)
-               if ((k < KMT[j][i]) && (k < KMT[j + 1][i]))
-                  VTN[k][j][i] += WORK[k][j][i] * DX[j][i];
-      free_2d_double (DX);
-      free_3d_double (WORK);
-   }
-   return VTN;
+         for (int i = 0; i < imt; i++)
+            if (k < KMT[j][i] && k < KMT[j + F->across_dj][(i + F->across_di) % imt]) T[k][j][i] += vel[k][j][i] * len[j][i];
+   free_2d_double (len);
+   free_3d_double (vel);
+   return T;
 }
 
+static double ***load_UTE (void) { return load_face_transport (&EAST_FACE); }
+static double ***load_VTN (void) { return load_face_transport (&NORTH_FACE); }
+
+/* vertical velocity at the top of every ocean cell: resolved plus, with hmix_hor_file, bolus; rigid lid at the surface */
 static double ***load_WVEL (void)
 {
-   char *subname = "load_WVEL";
-   double ***WVEL = zeros_3d ();
-   double ***WORK;
-   char *names[2] = { "WVEL", "WISOP" };
+   static const char *parts[2] = { "WVEL", "WISOP" };
+   const int nparts = (hmix_opt == hmix_hor_file) ? 2 : 1;
+   double ***W = zeros_3d ();
 
-   if (WVEL == NULL)
-      return NULL;
-   for (int pass = 0; pass < ((hmix_opt == hmix_hor_file) ? 2 : 1); pass++) {
-      if (dbg_lvl)
-         printf ("(%d) %s: reading %s from %s\n", iam, subname, names[pass], circ_fname);
-      if ((WORK = read_3d (circ_fname, names[pass], 1)) == NULL)
-         return NULL;
-      for (int k = 0; k < km; k++)
+   if (W == NULL) return NULL;
+   for (int q = 0; q < nparts; q++) {
+      double ***part;
+      if (dbg_lvl) printf ("(%d) load_WVEL: reading %s from %s\n", iam, parts[q], circ_fname);
+      if ((part = read_3d (circ_fname, (char *) parts[q], 1)) == NULL) return NULL;
+      for (int k = 1; k < km; k++)
          for (int j = 1; j < jmt - 1; j++)
             for (int i = 0; i < imt; i++)
-               if (k < KMT[j][i])
-                  WVEL[k][j][i] += WORK[k][j][i];
-      free_3d_double (WORK);
+               if (k < KMT[j][i]) W[k][j][i] += part[k][j][i];
+      free_3d_double (part);
    }
-   /* rigid lid: no flow through the surface */
-   for (int j = 1; j < jmt - 1; j++)
-      for (int i = 0; i < imt; i++)
-         WVEL[0][j][i] = 0.0;
-   return WVEL;
+   return W;
 }
 
 /* weights of the cell's own value in the face interpolation: 1/0 donor, 0.5 centred
