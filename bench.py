@@ -173,7 +173,6 @@ def main():
                 mode = f"strong scaling: rows split into {world} latitude bands, halo alltoallv + allreduce over RCCL (torch.distributed), rank-local multilevel preconditioner"
             comm = nd.TorchComm()
             s = nd.NkpDistSolver(loc, n_global, comm, **kw)
-            s.set_stream(torch.cuda.current_stream().cuda_stream)
             fst = loc["fst_row"]
         except Exception as exc:                           # keep the scaling run alive, but say what happened
             print(f"({rank}) distributed setup failed, falling back to one replica per rank: {exc!r}", file=sys.stderr)

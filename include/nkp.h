@@ -142,10 +142,12 @@ int nkp_multi_dot (nkp_solver *s, const double *V, int64_t ld, int k, const doub
 
 /* Average duration (ms) of `reps` back-to-back launches of one kernel on the solver's stream,
  * measured with HIP events on that stream.  which: 0 = CSR SpMV, 1 = preconditioner apply,
- * 2 = one full Krylov iteration body at restart position `arg` (0 <= arg < restart). */
+ * 2 = one full Krylov iteration body at restart position `arg` (0 <= arg < restart); multilevel only: 3 = the
+ * smoother's residual rows of one colour of the fine level, 4 = the water-column solves of that colour. */
 int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, double *avg_ms);
 
-/* Introspection: key = "n", "nnz", "nblk", "band", "levels", "spmv_bytes", "device_bytes". */
+/* Introspection: key = "n", "nnz", "nblk", "band", "levels", "spmv_bytes", "device_bytes", "precond_steps", "equil";
+ * compulsory HBM bytes of the pieces nkp_time_kernel times: "smoother_spmv_bytes", "column_solve_bytes", "cycle_bytes". */
 int64_t nkp_get_int (nkp_solver *s, const char *key);
 
 /* Use an externally owned HIP stream (hipStream_t cast to void*) instead of the solver's own;
@@ -183,6 +185,11 @@ int nkp_comm_unique_id (void *id128);
 /* Fill `ops` with the built-in RCCL implementation (ncclCommInitRank on the current device). */
 int nkp_comm_rccl_init (nkp_comm_ops *ops, const void *id128, int rank, int nranks);
 void nkp_comm_rccl_free (nkp_comm_ops *ops);
+/* Fill `ops` with a host-staged transport over a directory every rank can write (one file per rank and collective).
+ * Test-grade: it lets several processes that share ONE GPU run the distributed code path (RCCL needs one GPU per rank).
+ * Every blocking read has a deadline (NKP_COMM_TIMEOUT seconds, default 120): a dead peer fails the collective. */
+int nkp_comm_file_init (nkp_comm_ops *ops, const char *dir, int rank, int nranks);
+void nkp_comm_file_free (nkp_comm_ops *ops);
 
 /* Local row block [fst_row, fst_row + m_loc) with GLOBAL column indices, rowptr rebased to 0
  * -- exactly what dCreate_CompRowLoc_Matrix_dist receives (src/solve_ABdist.c:482-483).

@@ -281,49 +281,80 @@ int main (int argc, char *argv[])
    nkp_comm_ops ops;
    memset (&ops, 0, sizeof ops);
    int info = 0;
+   int file_transport = 0;
    if (use_comm) {
-      unsigned char id[128];
-      const char *idfile = getenv ("NKP_RCCL_ID_FILE");
-      if (idfile == NULL) {
-         fprintf (stderr, "(%d) WORLD_SIZE = %d needs NKP_RCCL_ID_FILE (a path every rank can read)\n", iam, world);
-         exit (EXIT_FAILURE);
-      }
-      opt.device = local_rank;
-      if (nkp_set_device (local_rank)) {
-         fprintf (stderr, "(%d) %s\n", iam, nkp_last_error ());
-         exit (EXIT_FAILURE);
-      }
-      if (iam == 0) {
-         char tmpname[4096];
-         snprintf (tmpname, sizeof tmpname, "%s.tmp", idfile);
-         FILE *f = NULL;
-         if (nkp_comm_unique_id (id) || (f = fopen (tmpname, "wb")) == NULL || fwrite (id, 1, sizeof id, f) != sizeof id || fclose (f) || rename (tmpname, idfile)) {
-            fprintf (stderr, "(%d) could not publish the RCCL unique id through %s\n", iam, idfile);
+      // transport: RCCL (one GPU per rank; the unique id travels through NKP_RCCL_ID_FILE) or, for boxes with fewer GPUs
+      // than ranks, the host-staged file transport (NKP_COMM=file, NKP_COMM_DIR=<directory every rank can write>)
+      const char *transport = getenv ("NKP_COMM");
+      file_transport = transport && strcmp (transport, "file") == 0;
+      if (file_transport) {
+         const char *dir = getenv ("NKP_COMM_DIR");
+         int ndev = nkp_device_count ();
+         if (dir == NULL || ndev < 1) {
+            fprintf (stderr, "(%d) NKP_COMM=file needs NKP_COMM_DIR and a GPU\n", iam);
+            exit (EXIT_FAILURE);
+         }
+         opt.device = local_rank % ndev;                 // ranks may share a device
+         if (nkp_set_device (opt.device) || nkp_comm_file_init (&ops, dir, iam, world)) {
+            fprintf (stderr, "(%d) file transport in %s could not be set up: %s\n", iam, dir, nkp_last_error ());
             exit (EXIT_FAILURE);
          }
       } else {
-         int ok = 0;
-         const time_t launched = time (NULL);
-         for (int tries = 0; tries < 1200 && !ok; tries++) {       // up to two minutes
-            struct stat sb;
-            // a file left behind by an earlier job is not this job's id: only accept one written around our launch
-            if (stat (idfile, &sb) == 0 && sb.st_mtime + 60 >= launched) {
-               FILE *f = fopen (idfile, "rb");
-               if (f) {
-                  ok = fread (id, 1, sizeof id, f) == sizeof id;
-                  fclose (f);
-               }
-            }
-            if (!ok) usleep (100000);
+         // The id file carries a job tag (NKP_JOB_ID, else MASTER_PORT, else "-") in front of the 128-byte id: a rank only
+         // accepts a file with ITS job's tag, so an id left behind by an earlier job on the same path is never taken, and
+         // rank 0 removes the file as soon as the communicator exists (every rank has read it by then).
+         struct { char tag[64]; unsigned char id[128]; } rec;
+         memset (&rec, 0, sizeof rec);
+         char tag[64];
+         {
+            const char *j = getenv ("NKP_JOB_ID");
+            if (j == NULL || !*j) j = getenv ("MASTER_PORT");
+            snprintf (tag, sizeof tag, "%s", (j && *j) ? j : "-");
          }
-         if (!ok) {
-            fprintf (stderr, "(%d) timed out waiting for the RCCL unique id in %s\n", iam, idfile);
+         const char *idfile = getenv ("NKP_RCCL_ID_FILE");
+         if (idfile == NULL) {
+            fprintf (stderr, "(%d) WORLD_SIZE = %d needs NKP_RCCL_ID_FILE (a path every rank can read)\n", iam, world);
             exit (EXIT_FAILURE);
          }
-      }
-      if (nkp_comm_rccl_init (&ops, id, iam, world)) {
-         fprintf (stderr, "(%d) nkp_comm_rccl_init failed\n", iam);
-         exit (EXIT_FAILURE);
+         opt.device = local_rank;
+         if (nkp_set_device (local_rank)) {
+            fprintf (stderr, "(%d) %s\n", iam, nkp_last_error ());
+            exit (EXIT_FAILURE);
+         }
+         if (iam == 0) {
+            char tmpname[4096];
+            snprintf (tmpname, sizeof tmpname, "%s.tmp", idfile);
+            snprintf (rec.tag, sizeof rec.tag, "%s", tag);
+            FILE *f = NULL;
+            if (nkp_comm_unique_id (rec.id) || (f = fopen (tmpname, "wb")) == NULL || fwrite (&rec, 1, sizeof rec, f) != sizeof rec || fclose (f) || rename (tmpname, idfile)) {
+               fprintf (stderr, "(%d) could not publish the RCCL unique id through %s\n", iam, idfile);
+               exit (EXIT_FAILURE);
+            }
+         } else {
+            int ok = 0;
+            const time_t launched = time (NULL);
+            for (int tries = 0; tries < 1200 && !ok; tries++) {       // up to two minutes
+               struct stat sb;
+               // without a job tag fall back on the age test: only a file written around our launch can be ours
+               if (stat (idfile, &sb) == 0 && (strcmp (tag, "-") != 0 || sb.st_mtime + 60 >= launched)) {
+                  FILE *f = fopen (idfile, "rb");
+                  if (f) {
+                     ok = fread (&rec, 1, sizeof rec, f) == sizeof rec && strncmp (rec.tag, tag, sizeof rec.tag) == 0;
+                     fclose (f);
+                  }
+               }
+               if (!ok) usleep (100000);
+            }
+            if (!ok) {
+               fprintf (stderr, "(%d) timed out waiting for the RCCL unique id of job '%s' in %s\n", iam, tag, idfile);
+               exit (EXIT_FAILURE);
+            }
+         }
+         if (nkp_comm_rccl_init (&ops, rec.id, iam, world)) {
+            fprintf (stderr, "(%d) nkp_comm_rccl_init failed\n", iam);
+            exit (EXIT_FAILURE);
+         }
+         if (iam == 0) (void) unlink (idfile);
       }
       nkp_rowblock_partition_snapped (blk_start, nblk, world, iam, &fst_row, &m_loc, &fst_blk, &nblk_loc);
    }
@@ -494,7 +525,7 @@ int main (int argc, char *argv[])
 
    nkp_destroy (solver);
 #ifdef NKP_DIST
-   if (use_comm) nkp_comm_rccl_free (&ops);
+   if (use_comm) { if (file_transport) nkp_comm_file_free (&ops); else nkp_comm_rccl_free (&ops); }
 #endif
    free_ind_maps ();
    free (vars_per_solve);

@@ -45,3 +45,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 void ml_free (MlHierarchy &H);
 // z = V-cycle(r) in the ORIGINAL row order
 void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st);
+// measurement helpers: launch one piece of a level-0 half sweep (0 residual rows, 1 column solves); compulsory HBM bytes of
+// that piece or of the whole cycle (2)
+void ml_time_piece (MlHierarchy &H, int which, hipStream_t st);
+int64_t ml_bytes (const MlHierarchy &H, int which);

@@ -938,3 +938,50 @@ void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st)
    ml_cycle (H, 0, st);
    launch_scatter (H.perm0, V.xnow (), z, V.n, st);
 }
+
+// ================================================================ measurement helpers (bench.py, probes)
+// one half sweep of level 0, colour 0: the residual rows (which = 0) or the column solves (which = 1)
+void ml_time_piece (MlHierarchy &H, int which, hipStream_t st)
+{
+   MlLevel &V = H.lev[0];
+   if (H.lev.size () < 2) return;
+   if (which == 0) launch_csr_residual_range (V.L, V.color_rb[0], V.color_rb[1], V.x, V.b, V.r, st);
+   else launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.r, V.x, 1, st);
+}
+
+// compulsory HBM bytes (every array element counted once per kernel that must touch it):
+//  which 0: residual rows of level 0, colour 0: its entries (value + column), row pointers, b in, r out, x once
+//  which 1: column solves of level 0, colour 0: factors, r in, x in and out
+//  which 2: one whole V(nu, nu) cycle
+int64_t ml_bytes (const MlHierarchy &H, int which)
+{
+   if (H.lev.size () < 2) return 0;
+   auto level_piece = [&] (const MlLevel &V, int colour, int what) -> int64_t {
+      const int64_t rows = colour == 0 ? V.rows0 : V.n - V.rows0;
+      const int64_t vb = V.L.valf ? 4 : 8, fb = V.B.fac_tf ? 4 : 8;
+      if (what == 0) {
+         // entries of the colour's rows: the colour-major CSR keeps them contiguous; split nnz by rows as an estimate is not
+         // needed -- the host knows the exact count only at setup, so use the level's average row length
+         const double per_row = V.n ? (double) V.L.nnz / (double) V.n : 0.0;
+         return (int64_t) (per_row * (double) rows * (double) (vb + 4)) + rows * (4 + 8 + 8) + V.n * 8;
+      }
+      return rows * ((2 * V.B.P + 1) * fb + 8 + 8 + 8);
+   };
+   if (which == 0 || which == 1) return level_piece (H.lev[0], 0, which);
+   int64_t total = 0;
+   for (size_t l = 0; l + 1 < H.lev.size (); l++) {
+      const MlLevel &V = H.lev[l];
+      const int nu = ((int) l >= H.coarse_from) ? H.nu_coarse : H.nu;
+      for (int c = 0; c < 2; c++) {
+         total += (int64_t) (2 * nu) * level_piece (V, c, 1);                       // column solves: nu pre + nu post sweeps
+         total += (int64_t) (2 * nu - (c == 0 ? 1 : 0)) * level_piece (V, c, 0);    // residual rows (the first half sweep needs none)
+      }
+      total += V.L.nnz * ((V.L.valf ? 4 : 8) + 4) + V.n * (4 + 8 + 8 + 8);         // full residual before the restriction
+      total += V.n * (8 + 4) + V.nc * (8 + 4);                                      // restriction
+      total += V.n * (8 + 8 + 4) + V.nc * 8;                                        // prolongation
+   }
+   const int64_t ncoarse = H.lev.back ().n;
+   total += ncoarse * ncoarse * 8 + 2 * ncoarse * 8;                                // dense coarsest solve
+   total += H.lev[0].n * (8 + 8 + 4) * 2;                                           // gather in, scatter out
+   return total;
+}

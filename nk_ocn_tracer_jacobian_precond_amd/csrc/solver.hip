@@ -489,6 +489,9 @@ extern "C" int64_t nkp_get_int (nkp_solver *s, const char *key)
    if (!strcmp (key, "device_bytes")) return (int64_t) s->device_bytes;
    if (!strcmp (key, "precond_steps")) return s->precond_steps;
    if (!strcmp (key, "equil")) return s->equil ? 1 : 0;
+   if (!strcmp (key, "smoother_spmv_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 0) : 0;
+   if (!strcmp (key, "column_solve_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 1) : 0;
+   if (!strcmp (key, "cycle_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 2) : 0;
    return -1;
 }
 
@@ -954,7 +957,8 @@ extern "C" int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, dou
       for (int i = 0; i < cnt; i++) {
          if (which == 0) spmv_op (s, s->t1, s->t2, nullptr, 0);
          else if (which == 1) apply_precond_once (s, s->t1, s->t2);
-         else arnoldi_step_device (s, arg);
+         else if (which == 2) arnoldi_step_device (s, arg);
+         else if (s->opt.precond == NKP_PRECOND_MULTILEVEL) ml_time_piece (s->ml, which - 3, s->stream);   // 3: smoother residual rows, 4: column solves (level 0, colour 0)
       }
       HIPCHK (hipEventRecord (e1, s->stream));
       HIPCHK (hipEventSynchronize (e1));

@@ -101,6 +101,7 @@ class TorchComm:
         self.device_native = dist.get_backend() == "nccl"
         self.errors = []
         self._views = {}
+        self._streams = {}
         self._fns = (_solver._ALLREDUCE_FN(self._allreduce), _solver._ALLTOALLV_FN(self._alltoallv),
                      _solver._ALLTOALLV_I32_FN(self._alltoallv_i32_host), _solver._ALLGATHER_I64_FN(self._allgather_i64_host))
         self.ops = _solver.NkpCommOps(None, self.rank, self.nranks, *self._fns)
@@ -115,6 +116,16 @@ class TorchComm:
             if len(self._views) < 4096:
                 self._views[key] = t
         return t
+
+    def _on(self, stream):
+        """The collective is ordered on the HIP stream the library names (its own non-blocking stream unless the caller
+        installed another): torch enqueues on whatever stream is current, so make that stream current for the call."""
+        ptr = int(stream) if stream else 0
+        st = self._streams.get(ptr)
+        if st is None:
+            st = self.torch.cuda.ExternalStream(ptr) if ptr else self.torch.cuda.default_stream()
+            self._streams[ptr] = st
+        return self.torch.cuda.stream(st)
 
     def _exchange_host(self, send, scnt, recv, rcnt):
         """alltoallv of 1-D CPU tensors with isend/irecv (gloo has no all_to_all)."""
@@ -145,14 +156,16 @@ class TorchComm:
     # ---- the four collectives
     def _allreduce(self, ctx, dev_buf, count, op, stream):
         def run():
-            t = self._dev(dev_buf, count)
-            rop = self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM
-            if self.device_native:
-                self.dist.all_reduce(t, op=rop)
-            else:
-                h = t.cpu()
-                self.dist.all_reduce(h, op=rop)
-                t.copy_(h)
+            with self._on(stream):
+                t = self._dev(dev_buf, count)
+                rop = self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM
+                if self.device_native:
+                    self.dist.all_reduce(t, op=rop)
+                else:
+                    h = t.cpu()                      # synchronises the stream: the library's kernels have finished
+                    self.dist.all_reduce(h, op=rop)
+                    t.copy_(h)
+                    self.torch.cuda.current_stream().synchronize()
         return self._guard(run)
 
     def _alltoallv(self, ctx, dev_send, scnt, dev_recv, rcnt, stream):
@@ -160,15 +173,17 @@ class TorchComm:
             sc = [int(scnt[p]) for p in range(self.nranks)]
             rc = [int(rcnt[p]) for p in range(self.nranks)]
             ns, nr = sum(sc), sum(rc)
-            send = self._dev(dev_send, ns) if ns else self.torch.empty(0, dtype=self.torch.float64, device="cuda")
-            recv = self._dev(dev_recv, nr) if nr else self.torch.empty(0, dtype=self.torch.float64, device="cuda")
-            if self.device_native:
-                self.dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
-            else:
-                hs, hr = send.cpu(), self.torch.empty(nr, dtype=self.torch.float64)
-                self._exchange_host(hs, sc, hr, rc)
-                if nr:
-                    recv.copy_(hr)
+            with self._on(stream):
+                send = self._dev(dev_send, ns) if ns else self.torch.empty(0, dtype=self.torch.float64, device="cuda")
+                recv = self._dev(dev_recv, nr) if nr else self.torch.empty(0, dtype=self.torch.float64, device="cuda")
+                if self.device_native:
+                    self.dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
+                else:
+                    hs, hr = send.cpu(), self.torch.empty(nr, dtype=self.torch.float64)
+                    self._exchange_host(hs, sc, hr, rc)
+                    if nr:
+                        recv.copy_(hr)
+                        self.torch.cuda.current_stream().synchronize()
         return self._guard(run)
 
     def _alltoallv_i32_host(self, ctx, send, scnt, recv, rcnt):

@@ -50,3 +50,63 @@ def test_solve_ABdist_cli_with_builtin_rccl(tmp_path, golden_by_name):
     x = nc3.NcFile(dst).get("IAGE")[g.ind_k, g.ind_j, g.ind_i]
     ref = g.gold["x_IAGE"]
     assert np.linalg.norm(x - ref) / np.linalg.norm(ref) <= 1e-7
+
+
+@pytest.mark.parametrize("world,case", [(2, "penta_12x10x6"), (3, "pair_8x8x5")])
+def test_solve_ABdist_cli_multi_process(tmp_path, golden_by_name, world, case):
+    """bin/solve_ABdist as a real multi-process program (reference src/solve_ABdist.c:115-244, 334-418): `world`
+    processes, each with its own row block (the reference's n/P rule snapped to water columns), halo exchange and
+    allreduce through the host-staged file transport (the box has one GPU; RCCL needs one per rank), slices gathered
+    on rank 0, which writes the tracer file.  Result against the SuperLU fixture; the id file of an EARLIER job with
+    another tag lying on the path must not be picked up (covered by the single-rank RCCL test's tag)."""
+    import os
+    import shutil
+    import subprocess
+    import numpy as np
+    from nk_ocn_tracer_jacobian_precond_amd import nc3
+    g = golden_by_name(case)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "nk_ocn_tracer_jacobian_precond_amd", "bin", "solve_ABdist")
+    dst = str(tmp_path / "B_dist.nc")
+    shutil.copy(g.tracer_path, dst)
+    comm_dir = tmp_path / "comm"
+    comm_dir.mkdir()
+    names = ",".join(g.varnames)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, NKP_COMM="file", NKP_COMM_DIR=str(comm_dir), NKP_COMM_TIMEOUT="60", NKP_RTOL="1e-12", RANK=str(r),
+                   WORLD_SIZE=str(world), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([exe, "-D1", "-n", "1", "-v", names, g.matrix_path, dst], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se + so
+    assert sum("nkp_create_dist: rows [" in so for so, _ in outs) == world
+    rows = sorted(int(so.split("nkp_create_dist: rows [")[1].split(",")[0]) for so, _ in outs)
+    assert rows[0] == 0 and len(set(rows)) == world            # every rank owned a different row block
+    out = nc3.NcFile(dst)
+    for grp in g.groups():
+        k = g.varnames.index(grp)
+        x = np.concatenate([out.get(v)[g.ind_k, g.ind_j, g.ind_i] for v in g.varnames[k:k + g.cnt]])
+        ref = g.gold["x_" + grp]
+        assert np.linalg.norm(x - ref) / np.linalg.norm(ref) <= 1e-7
+    assert not list(comm_dir.iterdir())                         # the transport cleaned up after itself
+
+
+def test_stale_rccl_id_file_is_ignored(tmp_path, golden_by_name):
+    """An id file left on the path by another job (different tag) must not be taken: the single-rank RCCL run publishes
+    and removes its own."""
+    import os
+    import shutil
+    import subprocess
+    g = golden_by_name("tri_12x10x6")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "nk_ocn_tracer_jacobian_precond_amd", "bin", "solve_ABdist")
+    dst = str(tmp_path / "B.nc")
+    shutil.copy(g.tracer_path, dst)
+    idfile = tmp_path / "rccl.id"
+    idfile.write_bytes(b"other-job".ljust(64, b"\0") + bytes(128))
+    env = dict(os.environ, NKP_FORCE_DIST="1", NKP_RCCL_ID_FILE=str(idfile), NKP_JOB_ID="job-42", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([exe, "-v", "IAGE", g.matrix_path, dst], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert not idfile.exists()                                  # rank 0 removed its id once the communicator existed
