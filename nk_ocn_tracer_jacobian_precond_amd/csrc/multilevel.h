@@ -33,6 +33,7 @@ struct MlHierarchy {
    int coarse_from = 2;
    int f32 = 1;                 // store level operators / factors in f32 (arithmetic stays f64)
    int fused = 1;               // one launch per Gauss-Seidel half sweep (gs_fused_kernel) where the level allows it
+   int tail_from = -1;          // levels >= tail_from run in ONE single-workgroup launch (mltail.hip); -1 = none
    int gamma_from = 0, gamma_to = 0;   // levels [from, to) apply the coarse-grid correction twice (W-cycle there)
    double omega = 0.0;          // scaling of the coarse-grid correction (0 = not read yet; NKP_ML_OMEGA, default 1)
    size_t device_bytes = 0;
@@ -49,3 +50,5 @@ void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st);
 // that piece or of the whole cycle (2)
 void ml_time_piece (MlHierarchy &H, int which, hipStream_t st);
 int64_t ml_bytes (const MlHierarchy &H, int which);
+// the sub-cycle of the levels >= l0 in one single-workgroup launch (mltail.hip); 0 = launched
+int ml_tail_launch (MlHierarchy &H, int l0, hipStream_t st);

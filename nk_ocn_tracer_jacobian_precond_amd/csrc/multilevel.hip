@@ -844,6 +844,19 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
                  (long long) prow[nl], ncol, N.ncol0, ncol - N.ncol0, l == nlev - 1 ? ", dense solve" : "");
       t_dev += secs (t_dev0);
    }
+   {
+      // the small end of the cycle in one single-workgroup launch: the last levels whose rows add up to <= NKP_ML_TAIL_ROWS
+      int64_t cap = 0;             // off: measured 1.7-5x SLOWER (1 degree cycle 4.57 against 2.68 ms) -- one workgroup is latency-bound on a single CU
+      if (const char *e = getenv ("NKP_ML_TAIL_ROWS")) cap = atoll (e);
+      H.tail_from = -1;
+      int64_t rows = 0;
+      for (int l = nlev - 1; l >= 0 && nlev - l <= 8; l--) {
+         rows += H.lev[l].n;
+         if (rows > cap) break;
+         if (l < nlev - 1) H.tail_from = l;           // at least two levels, else there is nothing to merge
+      }
+      if (verbose && H.tail_from >= 0) printf ("(%d) multilevel: levels %d..%d run as one single-workgroup launch\n", rank, H.tail_from, nlev - 1);
+   }
    if (verbose) {
       printf ("(%d) multilevel setup: %.2f s low-order twin, %.2f s column graphs, %.2f s Galerkin products, %.2f s colour-major permutation, "
               "%.2f s uploads + factorisation + lane layouts\n", rank, t_low, t_graph, t_galerkin, t_perm, t_dev);
@@ -899,6 +912,7 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
    }
    MlLevel &V = H.lev[l];
    V.cur[0] = V.cur[1] = 0;
+   if (l == H.tail_from && H.gamma_to <= H.gamma_from && ml_tail_launch (H, l, st) == 0) return;
    if (l == (int) H.lev.size () - 1) {
       launch_dense_matvec (H.coarse_inv, V.b, V.x, (int) V.n, st);
       return;

@@ -603,3 +603,33 @@ def test_fused_half_sweeps_are_bit_identical(case, medium, monkeypatch):
                 z[fused] = s.precond_apply(r)
         assert np.isfinite(z["1"]).all()
         assert np.array_equal(z["0"], z["1"]), (case, f32, np.abs(z["0"] - z["1"]).max())
+
+
+@pytest.mark.parametrize("case", ["medium", "tiny", "tracers2", "long_columns"])
+def test_tail_kernel_is_bit_identical(case, medium, golden_by_name, monkeypatch):
+    """ml_tail_kernel (the last levels of the V-cycle in one single-workgroup launch) against the ~30 launches per level
+    it replaces: same arithmetic in the same order => the same bits; also when the WHOLE hierarchy fits the tail."""
+    cnt = 1
+    if case == "medium":
+        p, blk = medium
+    elif case == "tiny":
+        p = synth.generate(imt=24, jmt=20, km=10, adv="upwind3", hmix="isop", seed=2)         # every level inside the tail
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    elif case == "tracers2":
+        p = synth.generate(imt=40, jmt=46, km=20, adv="upwind3", hmix="isop", coupled_tracer_cnt=2, seed=3)
+        cnt = 2
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, cnt)
+    else:
+        p = synth.generate(imt=24, jmt=20, km=70, adv="centred", hmix="const", seed=5)
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), cnt)
+    r = np.random.default_rng(29).standard_normal(p.flat_len)
+    for f32 in ("1", "0"):
+        monkeypatch.setenv("NKP_ML_F32", f32)
+        z = {}
+        for rows in ("0", "16000"):
+            monkeypatch.setenv("NKP_ML_TAIL_ROWS", rows)
+            with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, coupled_tracer_cnt=cnt, restart=4) as s:
+                z[rows] = s.precond_apply(r)
+        assert np.isfinite(z["16000"]).all()
+        assert np.array_equal(z["0"], z["16000"]), (case, f32, np.abs(z["0"] - z["16000"]).max())
