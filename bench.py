@@ -159,16 +159,39 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the solve path has no CPU fallback)")
+    backend = os.environ.get("NKP_BENCH_BACKEND", "nccl")      # "gloo": developer rehearsal of N ranks on fewer GPUs (host-staged collectives)
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if a.force_dist:
         os.environ["NKP_FORCE_DIST"] = "1"
         os.environ.setdefault("MASTER_PORT", "29511")
     if world > 1 or a.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from nk_ocn_tracer_jacobian_precond_amd import dist as nd
     from nk_ocn_tracer_jacobian_precond_amd import solver, synth
+
+    def all_reduce(t, op=dist.ReduceOp.SUM):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:                                            # gloo rehearsal: stage through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+
+    def all_gather(parts, mine):
+        if backend == "nccl":
+            all_gather(parts, mine)
+        else:
+            hp = [q.cpu() for q in parts]
+            dist.all_gather(hp, mine.cpu())
+            for q, h in zip(parts, hp):
+                q.copy_(h)
 
     imt, jmt, km = (int(t) for t in a.grid.split("x"))
     t0 = time.perf_counter()
@@ -224,7 +247,7 @@ def main():
             print(f"({rank}) distributed setup failed, falling back to one replica per rank: {exc!r}", file=sys.stderr)
             s = None
         ok = torch.tensor([1 if s is not None else 0], device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             s = None
             n_global, nnz_global, tracers_global = p.flat_len, p.nnz, 1     # replicas of the single-tracer problem
@@ -266,7 +289,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     # independent check of the last solution with torch's own SpMV (not the kernel under test)
@@ -280,7 +303,7 @@ def main():
                 mine = torch.zeros(pad, dtype=torch.float64, device="cuda")
                 mine[:v.numel()] = v
                 parts = [torch.empty(pad, dtype=torch.float64, device="cuda") for _ in range(world)]
-                dist.all_gather(parts, mine)
+                all_gather(parts, mine)
                 return torch.cat([parts[r][:sizes[r]] for r in range(world)])
             xg, bg = gather_padded(X[-1]), None
         else:
@@ -293,7 +316,7 @@ def main():
             At = torch.sparse_csr_tensor(crow, ccol, cval, size=(n, n_global))
             r = B[-1] - (At @ xg.unsqueeze(1)).squeeze(1)
             sq = torch.stack([torch.sum(r * r), torch.sum(B[-1] * B[-1])])
-            dist.all_reduce(sq)
+            all_reduce(sq)
             relres_check = float(torch.sqrt(sq[0] / sq[1]))
             del At, crow, ccol, cval, r
         else:

@@ -418,6 +418,82 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
       for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
 }
 
+
+// ================================================================ lane-per-column apply, 64 columns per wave, factors streamed
+// The 8-columns-per-wave kernel above keeps 56 of 64 lanes idle during the substitution and stages the factors through
+// LDS, which caps a CU at 11 waves; all of them load, then all of them compute, and HBM idles during the compute phase
+// (1 degree fine level: 44 us per colour for 93 MB = 2.1 TB/s).  Here a wave owns GW = 32 (or 64) columns: only the
+// right-hand side goes through LDS (coalesced staging of the group's contiguous rows), every lane below GW runs its own
+// substitution, and each step reads its factors straight from HBM/L2 as ONE coalesced 128- or 256-byte load per diagonal
+// ([diag][k][lane] layout) that the unrolled code requests many steps ahead (244 VGPRs: two waves per SIMD, all waves of
+// a colour resident at once).  Same operations in the same order => same bits as the other kernels.
+template <int P, int MAXL, class FT, int GW>
+__global__ __launch_bounds__ (NKP_WAVE)
+void colblock_apply_stream_kernel (const int *__restrict__ grp_nb, const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
+                                   const FT *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
+                                   const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp)
+{
+   extern __shared__ double lds[];            // the group's right-hand side, then its solution
+   constexpr int gw = GW;
+   const int g = blockIdx.x + g_first;
+   const int lane = threadIdx.x;
+   const int nb = grp_nb[g], ml = grp_maxlen[g];
+   const int R0 = grp_row0[g], nrows = grp_row0[ngrp + g];
+   int s = 0, len = 0;
+   if (lane < gw) { s = col_slot[g * gw + lane]; len = col_slot[(ngrp + g) * gw + lane]; }
+   const FT *ft = fac_t + grp_base[g] + lane;
+   const int dstride = ml * gw;
+   for (int i0 = lane; i0 < nrows; i0 += 8 * NKP_WAVE) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = (i0 + u * NKP_WAVE < nrows) ? rhs[(int64_t) R0 + i0 + u * NKP_WAVE] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+         if (i0 + u * NKP_WAVE < nrows) lds[LDS_PAD (i0 + u * NKP_WAVE)] = t[u];
+   }
+   __syncthreads ();
+   if (lane < nb) {
+      double v[MAXL];
+#pragma unroll
+      for (int k = 0; k < MAXL; k++) v[k] = (k < len) ? lds[LDS_PAD (s + k)] : 0.0;
+#pragma unroll
+      for (int k0 = 0; k0 < MAXL; k0 += 8) {
+         if (k0 < ml) {
+#pragma unroll
+            for (int k = k0; k < k0 + 8; k++) {
+               double y = v[k];
+#pragma unroll
+               for (int q = P; q >= 1; q--)
+                  if (k - q >= 0) y -= (double) ft[(P - q) * dstride + k * gw] * v[k - q];
+               v[k] = y;
+            }
+         }
+      }
+#pragma unroll
+      for (int k0 = MAXL - 8; k0 >= 0; k0 -= 8) {
+         if (k0 < ml) {
+#pragma unroll
+            for (int k = k0 + 7; k >= k0; k--) {
+               double x = v[k];
+#pragma unroll
+               for (int q = P; q >= 1; q--)
+                  if (k + q < MAXL) x -= (double) ft[(P + q) * dstride + k * gw] * v[k + q];
+               x *= (double) ft[P * dstride + k * gw];
+               v[k] = x;
+            }
+         }
+      }
+#pragma unroll
+      for (int k = 0; k < MAXL; k++)
+         if (k < len) lds[LDS_PAD (s + k)] = v[k];
+   }
+   __syncthreads ();
+   if (accumulate)
+      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] += lds[LDS_PAD (i)];
+   else
+      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
+}
+
 template <class T>
 static int up (T **dst, const std::vector<T> &src, size_t *bytes)
 {
@@ -444,7 +520,23 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    int gw = 8;
    if (const char *e = getenv ("NKP_COLGROUP")) gw = atoi (e);
    if (gw != 8 && gw != 16 && gw != 32 && gw != 64) gw = 8;
-   while (gw > 8 && (size_t) ((2 * B.P + 2) * ((B.max_len + 7) & ~7) * gw) * sizeof (double) > 56 * 1024) gw >>= 1;
+   // levels with many columns: 32 or 64 columns per wave, factors streamed from HBM instead of staged in LDS
+   // (colblock_apply_stream_kernel); NKP_COLSTREAM=0 disables, NKP_COLSTREAM_MIN = fewest columns of a level that uses it
+   {
+      // measured at 1 degree (93 MB per colour of the fine level): 8 columns per wave with LDS-staged factors 44.7 us,
+      // 64 streamed 33.6 us, 32 streamed 26.2 us (3.55 TB/s); on levels below ~50 000 columns the fewer, longer waves of
+      // the streamed kernel lose to the small-group kernel (whole cycle 2.69 -> 2.52 ms with the fine level only, 2.55 with
+      // the first two levels, 2.61 with three)
+      int on = 1, min_cols = 50000, sgw = 32;
+      if (const char *e = getenv ("NKP_COLSTREAM")) on = atoi (e) != 0;
+      if (const char *e = getenv ("NKP_COLSTREAM_MIN")) min_cols = atoi (e);
+      if (const char *e = getenv ("NKP_COLSTREAM_GW")) sgw = atoi (e) == 64 ? 64 : 32;
+      // the column lives in registers: beyond 64 levels the kernel needs all 256 VGPRs (one wave per SIMD) and loses --
+      // 0.25 degree x 80 levels: cycle 46.2 ms with it against 32.8 ms with the small-group kernel
+      B.stream = on && ranges[nranges] - ranges[0] >= min_cols && B.max_len <= 64;
+      if (B.stream) gw = sgw;
+   }
+   while (!B.stream && gw > 8 && (size_t) ((2 * B.P + 2) * ((B.max_len + 7) & ~7) * gw) * sizeof (double) > 56 * 1024) gw >>= 1;
    B.gw = gw;
    long long total = 0;
    int lds_need = 0, fac_need = 0;
@@ -495,7 +587,7 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    B.ngrp = (int) b0.size ();
    lds_need = (lds_need + 1) & ~1;                 // keep the factor area 16-byte aligned
    B.rhs_slots = lds_need;
-   lds_need += f32 ? (fac_need + 1) / 2 : fac_need;      // doubles
+   if (!B.stream) lds_need += f32 ? (fac_need + 1) / 2 : fac_need;      // doubles
    B.lds_doubles = lds_need;
    int rc;
    if ((rc = up (&B.grp_b0, b0, device_bytes)) || (rc = up (&B.grp_nb, nb, device_bytes)) || (rc = up (&B.grp_maxlen, ml, device_bytes)) ||
@@ -528,6 +620,13 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<PP, ML, double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
       (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<PP, ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
       LDS_OPT_IN (1, 64); LDS_OPT_IN (2, 64); LDS_OPT_IN (4, 64); LDS_OPT_IN (1, 128); LDS_OPT_IN (2, 128); LDS_OPT_IN (4, 128);
+#undef LDS_OPT_IN
+#define LDS_OPT_IN(PP, ML)                                                                                                              \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_stream_kernel<PP, ML, double, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_stream_kernel<PP, ML, float, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_stream_kernel<PP, ML, double, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_stream_kernel<PP, ML, float, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
+      LDS_OPT_IN (1, 64); LDS_OPT_IN (2, 64); LDS_OPT_IN (4, 64); LDS_OPT_IN (1, 96); LDS_OPT_IN (2, 96); LDS_OPT_IN (4, 96);
 #undef LDS_OPT_IN
    }
    return (int) hipStreamSynchronize (st);
@@ -849,6 +948,24 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
                                   B.fac_tf, r, z, accumulate, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp);
          return;
       }
+   }
+   if (B.stream) {
+#define STREAM_LAUNCH3(PP, ML, GG)                                                                                                                              \
+      do {                                                                                                                                                     \
+         if (B.fac_tf) hipLaunchKernelGGL ((colblock_apply_stream_kernel<PP, ML, float, GG>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.grp_nb, B.grp_maxlen,  \
+                                           B.grp_base, g0, B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp);                                         \
+         else hipLaunchKernelGGL ((colblock_apply_stream_kernel<PP, ML, double, GG>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.grp_nb, B.grp_maxlen,          \
+                                  B.grp_base, g0, B.fac_t, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp);                                                  \
+      } while (0)
+#define STREAM_LAUNCH2(PP, ML) do { if (B.gw == 32) STREAM_LAUNCH3 (PP, ML, 32); else STREAM_LAUNCH3 (PP, ML, 64); } while (0)
+#define STREAM_LAUNCH(PP) do { if (B.max_len <= 64) STREAM_LAUNCH2 (PP, 64); else STREAM_LAUNCH2 (PP, 96); } while (0)
+      if (B.P == 1) STREAM_LAUNCH (1);
+      else if (B.P == 2) STREAM_LAUNCH (2);
+      else STREAM_LAUNCH (4);
+#undef STREAM_LAUNCH
+#undef STREAM_LAUNCH2
+#undef STREAM_LAUNCH3
+      return;
    }
 #define LANES_LAUNCH(PP)                                                                                                   \
    do {                                                                                                                    \

@@ -68,6 +68,7 @@ struct ColBlocksDev {
    int gw = 64;                // columns (lanes in use) per group
    int rhs_slots = 0;          // LDS doubles reserved for the staged right-hand side
    // fused Gauss-Seidel half sweep (gs_fused_kernel): row blocks of every group's rows
+   int stream = 0;             // 1: 64 columns per wave, factors read straight from HBM (colblock_apply_stream_kernel)
    int gs_ok = 0;              // 1 if the level can run it (no row longer than GS_NNZ, LDS need within 64 KB)
    int gs_lds_bytes = 0;
    int *gs_rb_ptr = nullptr;   // [ngrp+1] first row-block boundary of the group

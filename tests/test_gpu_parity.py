@@ -633,3 +633,29 @@ def test_tail_kernel_is_bit_identical(case, medium, golden_by_name, monkeypatch)
                 z[rows] = s.precond_apply(r)
         assert np.isfinite(z["16000"]).all()
         assert np.array_equal(z["0"], z["16000"]), (case, f32, np.abs(z["0"] - z["16000"]).max())
+
+
+@pytest.mark.parametrize("case", ["medium", "long_columns", "wide_band"])
+def test_column_stream_kernel_is_bit_identical(case, medium, monkeypatch):
+    """colblock_apply_stream_kernel (64 water columns per wave, factors streamed from HBM) against the 8-columns-per-wave
+    kernel that stages them in LDS: the same substitutions in the same order => the same bits, as a preconditioner of its
+    own and inside the multilevel cycle."""
+    if case == "medium":
+        p, blk = medium
+    elif case == "long_columns":
+        p = synth.generate(imt=24, jmt=20, km=70, adv="centred", hmix="const", seed=5)
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    else:
+        p = synth.generate(imt=30, jmt=24, km=20, adv="upwind3", hmix="isop", seed=6)       # upwind3: in-column band of 2
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    r = np.random.default_rng(37).standard_normal(p.flat_len)
+    for precond, kw in ((solver.PRECOND_COLUMN_JACOBI, {}), (solver.PRECOND_MULTILEVEL, dict(col_i=ci, col_j=cj))):
+        z = {}
+        for stream in ("0", "1"):
+            monkeypatch.setenv("NKP_COLSTREAM", stream)
+            monkeypatch.setenv("NKP_COLSTREAM_MIN", "1")
+            with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, precond=precond, restart=4, **kw) as s:
+                z[stream] = s.precond_apply(r)
+        assert np.isfinite(z["1"]).all()
+        assert np.array_equal(z["0"], z["1"]), (case, precond, np.abs(z["0"] - z["1"]).max())
