@@ -112,6 +112,14 @@ int nkp_create (nkp_solver **out, const nkp_options *opt, int64_t n, int64_t nnz
                 const int32_t *rowptr, const int32_t *colind, const double *val,
                 const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt);
 
+/* Same with 64-bit row pointers (what a CDF-5 matrix file or a caller that counts entries in int64 holds).  Entry
+ * offsets are stored in 32 bits on the device, so ONE GPU takes at most 2^31 - 1 entries (25 GB of values and column
+ * indices); a larger system is row-partitioned with nkp_create_dist, where the limit applies to each rank's block --
+ * the 0.25 degree x 4 tracer system (4.2 G entries, n = 203 M < 2^31) is representable on 4 or 8 ranks.  Returns
+ * NKP_EINVAL with that explanation when rowptr[n] does not fit. */
+int nkp_create64 (nkp_solver **out, const nkp_options *opt, int64_t n, const int64_t *rowptr /* n+1 */,
+                  const int32_t *colind, const double *val, const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt);
+
 /* Solve nrhs systems; b (host, column-major, leading dimension ldb >= n) is overwritten by x
  * when the return code is NKP_OK or NKP_NOT_CONVERGED.  berr[r] receives the componentwise
  * backward error max_i |b-Ax|_i / (|A||x|+|b|)_i like SuperLU's; iters/relres per rhs.

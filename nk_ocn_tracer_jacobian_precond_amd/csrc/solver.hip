@@ -461,6 +461,23 @@ extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt, int64_t n, 
    return create_impl (out, opt, n, nnz, rowptr, colind, val, blk_start, nblk, coupled_tracer_cnt, nullptr);
 }
 
+extern "C" int nkp_create64 (nkp_solver **out, const nkp_options *opt, int64_t n, const int64_t *rowptr, const int32_t *colind, const double *val,
+                             const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt)
+{
+   if (!out) return fail (NKP_EINVAL, "nkp_create64: out is NULL");
+   *out = nullptr;
+   if (n < 0 || !rowptr) return fail (NKP_EINVAL, "nkp_create64: bad matrix arguments");
+   if (n >= 2147483647LL || rowptr[n] >= 2147483647LL || rowptr[n] < 0)
+      return fail (NKP_EINVAL, "nkp_create64: %lld rows / %lld entries: one GPU stores entry offsets in 32 bits (at most 2^31 - 1 rows and entries); "
+                   "row-partition the system with nkp_create_dist, where the limit applies per rank", (long long) n, (long long) rowptr[n]);
+   std::vector<int32_t> rp ((size_t) n + 1);
+   for (int64_t r = 0; r <= n; r++) {
+      if (rowptr[r] < 0 || rowptr[r] > rowptr[n]) return fail (NKP_EINVAL, "nkp_create64: rowptr[%lld] = %lld out of range", (long long) r, (long long) rowptr[r]);
+      rp[(size_t) r] = (int32_t) rowptr[r];
+   }
+   return create_impl (out, opt, n, rowptr[n], rp.data (), colind, val, blk_start, nblk, coupled_tracer_cnt, nullptr);
+}
+
 extern "C" int nkp_set_stream (nkp_solver *s, void *hip_stream)
 {
    if (!s) return fail (NKP_EINVAL, "nkp_set_stream: NULL solver");

@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "nkp_get_int", "nkp_set_stream", "nkp_destroy", "nkp_last_error", "nkp_comm_unique_id",
     "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host", "nkp_set_device",
     "nkp_gather_root", "nkp_clone", "nkp_ml_plan_host", "nkp_comm_file_init", "nkp_comm_file_free",
+    "nkp_create64",
 ]
 
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
@@ -75,6 +76,7 @@ def load_library(path=None):
     lib.nkp_default_options.argtypes = [C.POINTER(NkpOptions)]
     lib.nkp_device_count.restype = C.c_int
     lib.nkp_create.argtypes = [C.POINTER(vp), C.POINTER(NkpOptions), C.c_int64, C.c_int64, i32p, i32p, f64p, i32p, C.c_int64, C.c_int]
+    lib.nkp_create64.argtypes = [C.POINTER(vp), C.POINTER(NkpOptions), C.c_int64, C.POINTER(C.c_int64), i32p, f64p, i32p, C.c_int64, C.c_int]
     lib.nkp_solve.argtypes = [vp, f64p, C.c_int, C.c_int64, f64p, C.POINTER(C.c_int), f64p]
     lib.nkp_solve_device.argtypes = [vp, vp, vp, C.c_int, f64p, C.POINTER(C.c_int), f64p]
     lib.nkp_spmv.argtypes = [vp, f64p, f64p]
@@ -158,7 +160,9 @@ class NkpSolver:
     def __init__(self, rowptr, colind, val, blk_start=None, coupled_tracer_cnt=1, col_i=None, col_j=None, **options):
         self._lib = load_library()
         self._h = C.c_void_p()
-        rowptr = np.ascontiguousarray(rowptr, np.int32)
+        # 64-bit row pointers (CDF-5 matrix files, callers counting entries in int64) go through nkp_create64
+        self._rowptr64 = np.ascontiguousarray(rowptr, np.int64) if np.asarray(rowptr).dtype == np.int64 else None
+        rowptr = np.ascontiguousarray(rowptr, np.int32) if self._rowptr64 is None else self._rowptr64
         colind = np.ascontiguousarray(colind, np.int32)
         val = np.ascontiguousarray(val, np.float64)
         self.n = int(rowptr.size - 1)
@@ -176,8 +180,12 @@ class NkpSolver:
             bp, nb = _p(blk_start, C.c_int32), blk_start.size - 1
         else:
             bp, nb = None, 0
-        rc = self._lib.nkp_create(C.byref(self._h), C.byref(opt), self.n, self.nnz, _p(rowptr, C.c_int32),
-                                  _p(colind, C.c_int32), _p(val, C.c_double), bp, nb, coupled_tracer_cnt)
+        if self._rowptr64 is not None:
+            rc = self._lib.nkp_create64(C.byref(self._h), C.byref(opt), self.n, _p(self._rowptr64, C.c_int64),
+                                        _p(colind, C.c_int32), _p(val, C.c_double), bp, nb, coupled_tracer_cnt)
+        else:
+            rc = self._lib.nkp_create(C.byref(self._h), C.byref(opt), self.n, self.nnz, _p(rowptr, C.c_int32),
+                                      _p(colind, C.c_int32), _p(val, C.c_double), bp, nb, coupled_tracer_cnt)
         if rc != 0:
             self._h = C.c_void_p()
             raise NkpError(rc, self._lib.nkp_last_error().decode())

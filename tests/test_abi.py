@@ -69,3 +69,19 @@ def test_product_does_not_reference_the_oracle():
     for so in ("csrc/libnkp_hip.so", "host/libnkp_host.so"):
         needed = subprocess.run(["readelf", "-d", os.path.join(pkg, so)], capture_output=True, text=True).stdout
         assert "oracle" not in needed
+
+
+def test_create64_refuses_what_one_gpu_cannot_index():
+    """nkp_create64 (64-bit row pointers): more than 2^31 - 1 entries are refused with the way out (row-partition with
+    nkp_create_dist) before any device is touched, so this runs without a GPU."""
+    import ctypes as C
+    import numpy as np
+    from nk_ocn_tracer_jacobian_precond_amd import solver
+    lib = solver.load_library()
+    rp = np.array([0, 2 ** 31 + 5], np.int64)
+    h = C.c_void_p()
+    rc = lib.nkp_create64(C.byref(h), None, 1, rp.ctypes.data_as(C.POINTER(C.c_int64)), None, None, None, 0, 1)
+    assert rc == -1 and "nkp_create_dist" in solver.last_error() and not h.value
+    rp = np.array([0, 3, 2], np.int64)
+    rc = lib.nkp_create64(C.byref(h), None, 2, rp.ctypes.data_as(C.POINTER(C.c_int64)), None, None, None, 0, 1)
+    assert rc == -1 and "out of range" in solver.last_error()

@@ -40,6 +40,16 @@ def test_multilevel_cycle_is_a_fixed_linear_operator(medium):
         assert np.all(np.isfinite(z1)) and np.linalg.norm(z1) > 0
 
 
+def test_int64_row_pointers(golden_by_name):
+    """nkp_create64: the same matrix with 64-bit row pointers gives the same solver."""
+    g = golden_by_name("penta_12x10x6")
+    b = g.rhs(g.groups()[0])
+    with solver.NkpSolver(g.rowptr.astype(np.int64), g.colind, g.val, g.blk_start, coupled_tracer_cnt=g.cnt, rtol=1e-12) as s64, \
+            solver.NkpSolver(g.rowptr, g.colind, g.val, g.blk_start, coupled_tracer_cnt=g.cnt, rtol=1e-12) as s32:
+        assert np.array_equal(s64.spmv(b), s32.spmv(b))
+        assert np.array_equal(s64.solve(b)[0], s32.solve(b)[0])
+
+
 def test_gpu_present():
     assert solver.device_count() >= 1
 
