@@ -72,60 +72,56 @@ void for_row_chunks (int64_t n, F fn)
 }
 
 // ---------------------------------------------------------------- low-order twin
-// L = A + D - diag(rowsum D), D_ij = max(0, -a_ij, -a_ji) for i, j in different columns
+// L = A + D - diag(rowsum D), D_ij = max(0, -a_ij, -a_ji) for i, j in different columns.  Rows are sorted by column, so
+// a_ji is found by bisection in row j (no transpose); three row-parallel passes: new values and kept-entry counts,
+// prefix sum, fill.  Entries whose coupling becomes exactly zero are not stored.
 void build_low_order (int64_t n, const int *rowptr, const int *colind, const double *val, const std::vector<int> &col_of, HostCsr &L)
 {
    const int64_t nnz = rowptr[n];
-   // transpose (values + row ids), rows of T sorted by column because A is scanned in row order
-   std::vector<int> tptr (n + 1, 0), tcol (nnz);
-   std::vector<double> tval (nnz);
-   for (int64_t e = 0; e < nnz; e++) tptr[colind[e] + 1]++;
-   for (int64_t r = 0; r < n; r++) tptr[r + 1] += tptr[r];
-   {
-      std::vector<int> fill (tptr.begin (), tptr.end () - 1);
-      for (int64_t r = 0; r < n; r++)
-         for (int e = rowptr[r]; e < rowptr[r + 1]; e++) {
-            const int q = fill[colind[e]]++;
-            tcol[q] = (int) r;
-            tval[q] = val[e];
+   std::vector<double> nv ((size_t) nnz);
+   std::vector<int> keep ((size_t) n + 1, 0);
+   for_row_chunks (n, [&] (int, int64_t r0, int64_t r1) {
+      for (int64_t i = r0; i < r1; i++) {
+         double dsum = 0.0;
+         int diag_pos = -1, cnt = 0;
+         for (int e = rowptr[i]; e < rowptr[i + 1]; e++) {
+            const int j = colind[e];
+            double a = val[e];
+            if (j == i) { diag_pos = e; nv[e] = a; cnt++; continue; }
+            if (col_of[j] != col_of[i]) {
+               const int *lo = colind + rowptr[j], *hi = colind + rowptr[j + 1];
+               const int *q = std::lower_bound (lo, hi, (int) i);
+               const double aji = (q < hi && *q == (int) i) ? val[q - colind] : 0.0;
+               double d = 0.0;
+               if (-a > d) d = -a;
+               if (-aji > d) d = -aji;
+               a += d;
+               dsum += d;
+            }
+            nv[e] = a;
+            if (a != 0.0 || col_of[j] == col_of[i]) cnt++;          // in-column entries are always stored
          }
-   }
-   L.n = n;
-   L.rowptr.assign (n + 1, 0);
-   L.colind.clear ();
-   L.val.clear ();
-   L.colind.reserve (nnz);
-   L.val.reserve (nnz);
-   for (int64_t i = 0; i < n; i++) {
-      double dsum = 0.0;
-      int64_t diag_pos = -1;
-      int t = tptr[i];
-      const int tend = tptr[i + 1];
-      for (int e = rowptr[i]; e < rowptr[i + 1]; e++) {
-         const int j = colind[e];
-         double a = val[e];
-         if (j == i) {
-            diag_pos = (int64_t) L.colind.size ();
-            L.colind.push_back (j);
-            L.val.push_back (a);
-            continue;
-         }
-         if (col_of[j] != col_of[i]) {
-            while (t < tend && tcol[t] < j) t++;
-            const double aji = (t < tend && tcol[t] == j) ? tval[t] : 0.0;
-            double d = 0.0;
-            if (-a > d) d = -a;
-            if (-aji > d) d = -aji;
-            a += d;
-            dsum += d;
-            if (a == 0.0) continue;          // the removed (now zero) coupling is not stored
-         }
-         L.colind.push_back (j);
-         L.val.push_back (a);
+         if (diag_pos >= 0) nv[diag_pos] -= dsum;
+         keep[(size_t) i + 1] = cnt;
       }
-      if (diag_pos >= 0) L.val[diag_pos] -= dsum;
-      L.rowptr[i + 1] = (int) L.colind.size ();
-   }
+   });
+   L.n = n;
+   L.rowptr.assign ((size_t) n + 1, 0);
+   for (int64_t i = 0; i < n; i++) L.rowptr[(size_t) i + 1] = L.rowptr[(size_t) i] + keep[(size_t) i + 1];
+   L.colind.resize ((size_t) L.rowptr[(size_t) n]);
+   L.val.resize ((size_t) L.rowptr[(size_t) n]);
+   for_row_chunks (n, [&] (int, int64_t r0, int64_t r1) {
+      for (int64_t i = r0; i < r1; i++) {
+         int q = L.rowptr[(size_t) i];
+         for (int e = rowptr[i]; e < rowptr[i + 1]; e++) {
+            const int j = colind[e];
+            if (j != i && col_of[j] != col_of[i] && nv[e] == 0.0) continue;
+            L.colind[(size_t) q] = j;
+            L.val[(size_t) q] = nv[e];
+            q++;
+         }
+      }
+   });
 }
 
 // ---------------------------------------------------------------- column graph helpers
@@ -261,62 +257,74 @@ void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const
    const int ncol = (int) blk_start.size () - 1;
    auto depth = [&] (int r) { const int c = col_of[r]; return ktop[c] + (r - blk_start[c]); };
    auto row_at = [&] (int c, int k) -> int { const int r = blk_start[c] + (k - ktop[c]); return (k >= ktop[c] && r < blk_start[c + 1]) ? r : -1; };
-   // per row: diagonal and strongest lateral coupling; per column: how strongly any outside row of the same tracer feels it
-   std::vector<double> diag (n, 0.0), rowmax (n, 0.0), felt (ncol, 0.0), best (ncol, -1.0);
+   // per row: strongest lateral coupling (only needed for a threshold theta > 0); per column: how strongly any outside
+   // row of the same tracer feels it, and its own strongest coupling (only needed where stub columns exist)
+   bool have_stubs = false;
+   for (int c = 0; c < ncol && !have_stubs; c++) have_stubs = ktop[c] > 0;
+   std::vector<double> diag, rowmax, felt, best;
    std::vector<int> anchor (ncol, -1);
-   for (int64_t r = 0; r < n; r++)
-      for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++)
-         if (L.colind[e] == r) diag[r] = fabs (L.val[e]);
-   for (int64_t r = 0; r < n; r++) {
-      const int c = col_of[r];
-      for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++) {
-         const int j = L.colind[e], c2 = col_of[j];
-         if (c2 == c || col_t[c2] != col_t[c]) continue;
-         const double v = fabs (L.val[e]);
-         if (v > rowmax[r]) rowmax[r] = v;
-         const double f = diag[r] > 0.0 ? v / diag[r] : 1.0e300;
-         if (f > felt[c2]) felt[c2] = f;
-         if (v >= best[c]) { best[c] = v; anchor[c] = j; }          // strongest coupling of the column, ties -> later entry
-      }
-   }
    std::vector<char> dang (ncol, 0);
-   for (int c = 0; c < ncol; c++) dang[c] = (tau > 0.0 && ktop[c] > 0 && felt[c] < tau && anchor[c] >= 0);
-   {
+   if (theta > 0.0) {
+      rowmax.assign (n, 0.0);
+      for (int64_t r = 0; r < n; r++)
+         for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++) {
+            const int c2 = col_of[L.colind[e]];
+            if (c2 != col_of[r] && col_t[c2] == col_t[col_of[r]]) rowmax[r] = std::max (rowmax[r], fabs (L.val[e]));
+         }
+   }
+   if (have_stubs && tau > 0.0) {
+      diag.assign (n, 0.0);
+      felt.assign (ncol, 0.0);
+      best.assign (ncol, -1.0);
+      for (int64_t r = 0; r < n; r++)
+         for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++)
+            if (L.colind[e] == r) diag[r] = fabs (L.val[e]);
+      for (int64_t r = 0; r < n; r++) {
+         const int c = col_of[r];
+         for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++) {
+            const int j = L.colind[e], c2 = col_of[j];
+            if (c2 == c || col_t[c2] != col_t[c]) continue;
+            if (ktop[c2] == 0 && ktop[c] == 0) continue;                // neither end is a stub
+            const double v = fabs (L.val[e]);
+            const double f = diag[r] > 0.0 ? v / diag[r] : 1.0e300;
+            if (f > felt[c2]) felt[c2] = f;
+            if (v >= best[c]) { best[c] = v; anchor[c] = j; }          // strongest coupling of the column, ties -> later entry
+         }
+      }
+      for (int c = 0; c < ncol; c++) dang[c] = (ktop[c] > 0 && felt[c] < tau && anchor[c] >= 0);
       std::vector<char> bad (ncol, 0);
       for (int c = 0; c < ncol; c++) bad[c] = dang[c] && dang[col_of[anchor[c]]];
       for (int c = 0; c < ncol; c++) if (bad[c]) dang[c] = 0;
    }
-   // lateral edges between cells of the same depth
-   struct Edge { int a, b; bool same; };
-   std::vector<Edge> edges;
-   edges.reserve ((size_t) n * 2);
-   for (int64_t r = 0; r < n; r++) {
+   // lateral edges between cells of the same depth, united on the fly: U0 over all of them (it finds the small same-depth
+   // sets = pockets), U over the edges inside a group; a second scan of the pockets' rows adds their cross-group edges to U
+   UnionFind U (n), U0 (pocket > 0 ? n : 0);
+   auto scan_row = [&] (int64_t r, auto &&visit) {
       const int c = col_of[r];
-      if (dang[c]) continue;
+      if (dang[c]) return;
       const int k = depth ((int) r);
       for (int e = L.rowptr[r]; e < L.rowptr[r + 1]; e++) {
          const int j = L.colind[e], c2 = col_of[j];
          if (c2 == c || dang[c2] || col_t[c2] != col_t[c]) continue;
          const int dk = depth (j) - k;
          if (dk < -1 || dk > 1) continue;
-         if (fabs (L.val[e]) < theta * rowmax[r]) continue;
+         if (theta > 0.0 && fabs (L.val[e]) < theta * rowmax[r]) continue;
          const int t = row_at (c2, k);
-         if (t < 0) continue;
-         edges.push_back ({ (int) r, t, group[c] == group[c2] });
+         if (t >= 0) visit ((int) r, t, group[c] == group[c2]);
       }
-   }
-   UnionFind U (n);
+   };
+   for (int64_t r = 0; r < n; r++)
+      scan_row (r, [&] (int a, int b, bool same) {
+         if (pocket > 0) U0.unite (a, b);
+         if (same) U.unite (a, b);
+      });
    if (pocket > 0) {
-      UnionFind U0 (n);
-      for (const Edge &e : edges) U0.unite (e.a, e.b);
       std::vector<int> size (n, 0);
       for (int64_t r = 0; r < n; r++) size[U0.find ((int) r)]++;
-      for (const Edge &e : edges)
-         if (e.same || size[U0.find (e.a)] <= pocket) U.unite (e.a, e.b);
-   } else
-      for (const Edge &e : edges) if (e.same) U.unite (e.a, e.b);
-   edges.clear ();
-   edges.shrink_to_fit ();
+      for (int64_t r = 0; r < n; r++)
+         if (size[U0.find ((int) r)] <= pocket && size[U0.find ((int) r)] > 1)
+            scan_row (r, [&] (int a, int b, bool same) { if (!same) U.unite (a, b); });
+   }
    // components numbered in order of their lowest row
    std::vector<int> comp (n, -1);
    int ncomp = 0;
@@ -535,8 +543,8 @@ void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, cons
       Nat &N = nat[l];
       const int ncol = (int) N.blk_start.size () - 1;
       ColGraph G;
-      { auto t0 = clk::now (); build_col_graph (N.L, N.blk_start, N.col_of, G); t_graph += secs (t0); }
       const bool geo = !N.gi.empty ();
+      if (!geo) { auto t0 = clk::now (); build_col_graph (N.L, N.blk_start, N.col_of, G); t_graph += secs (t0); }
       if (geo) {
          N.colour.resize (ncol);
          for (int c = 0; c < ncol; c++) N.colour[c] = (N.gi[c] + N.gj[c]) & 1;
@@ -663,6 +671,7 @@ extern "C" int nkp_ml_plan_host (int64_t n, const int32_t *rowptr, const int32_t
    std::vector<Nat> nat;
    SetupTimes T;
    build_nat_levels (nat, n, rowptr, colind, val, blk_start, nblk, col_i, col_j, coupled_tracer_cnt, max_levels, coarsest_rows, 0, 0, T);
+   if (getenv ("NKP_ML_PLAN_TIMES")) printf ("nkp_ml_plan_host: %.2f s low-order twin, %.2f s graphs + aggregation, %.2f s Galerkin products\n", T.low, T.graph, T.galerkin);
    *n_levels = (int) nat.size ();
    int64_t qc = 0, qo = 0;
    for (size_t l = 0; l < nat.size (); l++) {
