@@ -149,7 +149,9 @@ void colblock_factor_kernel (const int *__restrict__ rowptr, const int *__restri
 }
 
 // ---------------------------------------------------------------- apply  z = (LU)^-1 r
-template <int P, int RPL>
+// R32: the factors are rounded to f32 on the way in, which gives exactly the values the f32 lane layouts store, so the
+// result is the one of the lane-per-column kernels in the f32-storage mode of the multilevel cycle
+template <int P, int RPL, bool R32 = false>
 __global__ __launch_bounds__ (CB_THREADS)
 void colblock_apply_kernel (const int *__restrict__ blk_start, int b_first, int nblk, int64_t n,
                             const double *__restrict__ fac, const double *__restrict__ rhs, double *__restrict__ z, int accumulate)
@@ -172,10 +174,12 @@ void colblock_apply_kernel (const int *__restrict__ blk_start, int b_first, int 
          const int64_t r = r0 + li;
          y[s] = rhs[r];
          invd[s] = fac[(int64_t) P * n + r];
+         if (R32) invd[s] = (double) (float) invd[s];
 #pragma unroll
          for (int q = 1; q <= P; q++) {
             L[s][q - 1] = fac[(int64_t) (P - q) * n + r];     // l(r, r-q)
             U[s][q - 1] = fac[(int64_t) (P + q) * n + r];     // u(r, r+q)
+            if (R32) { L[s][q - 1] = (double) (float) L[s][q - 1]; U[s][q - 1] = (double) (float) U[s][q - 1]; }
          }
       }
    }
@@ -262,6 +266,19 @@ void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const d
 {
    if (b1 <= b0) return;
    CB_DISPATCH_N (colblock_apply_kernel, b1 - b0, B.blk_start, b0, b1, B.n, B.fac, r, z, accumulate);
+}
+
+// same with the factors rounded to f32 on load (multilevel cycle with f32 storage)
+void launch_colblock_apply_range_r32 (const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, hipStream_t st)
+{
+   if (b1 <= b0) return;
+   const int rpl = B.max_len <= NKP_WAVE ? 1 : 2;
+   const dim3 grid = cb_grid (b1 - b0);
+#define R32_GO(PP, RR) hipLaunchKernelGGL ((colblock_apply_kernel<PP, RR, true>), grid, dim3 (CB_THREADS), 0, st, B.blk_start, b0, b1, B.n, B.fac, r, z, accumulate)
+   if (B.P == 1) { if (rpl == 1) R32_GO (1, 1); else R32_GO (1, 2); }
+   else if (B.P == 2) { if (rpl == 1) R32_GO (2, 1); else R32_GO (2, 2); }
+   else { if (rpl == 1) R32_GO (4, 1); else R32_GO (4, 2); }
+#undef R32_GO
 }
 
 // ================================================================ lane-per-column apply

@@ -822,6 +822,9 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
             const int ranges[3] = { 0, N.ncol0, ncol };
             const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st, H.f32, H.fused ? prow.data () : nullptr);
             if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
+            static int wave_max = -1;
+            if (wave_max < 0) { const char *e = getenv ("NKP_COLWAVE_MAX"); wave_max = e ? atoi (e) : 8192; }
+            V.wave_columns = ncol <= wave_max && V.B.dropped == 0;
          }
          // transfer operators in permuted orders
          Nat &C = nat[l + 1];
@@ -893,7 +896,19 @@ void ml_free (MlHierarchy &H)
 // one Gauss-Seidel half sweep over colour c.  Fused path: one launch, x ping-pongs between the level's two buffers (the
 // new values of colour c go where the other colour's current values are if the level is incoherent, else to the other
 // buffer).  Two-kernel path: residual SpMV of the colour's rows, then the column solves accumulate into x in place.
-static void gs_half (MlLevel &V, int c, bool fused, hipStream_t st)
+// column solves of colour c: levels with few columns run one column per WAVE (colblock_apply_kernel: one round trip for the
+// column's right-hand side and factors, the substitution by lane broadcasts) -- with thousands of idle wave slots its
+// ~5 us beat the 12-16 us latency floor of the lane-per-column kernels, which only win when the chip is full
+static void column_solves (const MlHierarchy &H, MlLevel &V, int c, const double *rhs, double *x, int accumulate, hipStream_t st)
+{
+   if (V.wave_columns) {
+      if (H.f32) launch_colblock_apply_range_r32 (V.B, V.color_blk[c], V.color_blk[c + 1], rhs, x, accumulate, st);
+      else launch_colblock_apply_range (V.B, V.color_blk[c], V.color_blk[c + 1], rhs, x, accumulate, st);
+   } else
+      launch_colblock_apply_lanes (V.B, V.color_grp[c], V.color_grp[c + 1], rhs, x, accumulate, st);
+}
+
+static void gs_half (const MlHierarchy &H, MlLevel &V, int c, bool fused, hipStream_t st)
 {
    if (fused) {
       const int out = (V.cur[0] != V.cur[1]) ? V.cur[1 - c] : 1 - V.cur[c];
@@ -903,12 +918,12 @@ static void gs_half (MlLevel &V, int c, bool fused, hipStream_t st)
       return;
    }
    launch_csr_residual_range (V.L, V.color_rb[c], V.color_rb[c + 1], V.x, V.b, V.r, st);
-   launch_colblock_apply_lanes (V.B, V.color_grp[c], V.color_grp[c + 1], V.r, V.x, 1, st);
+   column_solves (H, V, c, V.r, V.x, 1, st);
 }
 
-static void gs_sweep (MlLevel &V, bool reverse, bool fused, hipStream_t st)
+static void gs_sweep (const MlHierarchy &H, MlLevel &V, bool reverse, bool fused, hipStream_t st)
 {
-   for (int step = 0; step < 2; step++) gs_half (V, reverse ? 1 - step : step, fused, st);
+   for (int step = 0; step < 2; step++) gs_half (H, V, reverse ? 1 - step : step, fused, st);
 }
 
 static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
@@ -934,13 +949,13 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
       // sweeps that follows (colour 1, then nu - 1 full sweeps) ends coherent
       launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.b, V.x2, 0, st);
       V.cur[0] = 1;
-      gs_half (V, 1, true, st);
+      gs_half (H, V, 1, true, st);
    } else {
-      launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.b, V.x, 0, st);
-      gs_half (V, 1, false, st);
+      column_solves (H, V, 0, V.b, V.x, 0, st);
+      gs_half (H, V, 1, false, st);
    }
    const int nu = (l >= H.coarse_from) ? H.nu_coarse : H.nu;
-   for (int s = 1; s < nu; s++) gs_sweep (V, false, fused, st);
+   for (int s = 1; s < nu; s++) gs_sweep (H, V, false, fused, st);
    // coarse-grid correction; levels in [gamma_from, gamma_to) repeat it on the updated residual, which by the
    // Galerkin property is the second coarse iteration of a W-cycle (NKP_ML_GAMMA_FROM / NKP_ML_GAMMA_TO, default off)
    MlLevel &C = H.lev[l + 1];
@@ -951,7 +966,7 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
       ml_cycle (H, l + 1, st);
       launch_prolong_add (V.cmap, C.xnow (), V.xnow (), V.n, H.omega, st);
    }
-   for (int s = 0; s < nu; s++) gs_sweep (V, true, fused, st);
+   for (int s = 0; s < nu; s++) gs_sweep (H, V, true, fused, st);
 }
 
 void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st)

@@ -99,6 +99,7 @@ void launch_colblock_factor (const CsrDev &A, ColBlocksDev &B, int *d_status, hi
 void launch_colblock_apply (const ColBlocksDev &B, const double *r, double *z, hipStream_t st);
 // blocks [b0, b1) only; accumulate: z_blk += M_blk^-1 r_blk, else z_blk = M_blk^-1 r_blk
 void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, hipStream_t st);
+void launch_colblock_apply_range_r32 (const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, hipStream_t st);
 
 // ---------------------------------------------------------------- BLAS-1 style kernels
 #define NKP_RED_BLOCKS 1024        // partial sums per reduction (fixed => deterministic)

@@ -669,3 +669,29 @@ def test_column_stream_kernel_is_bit_identical(case, medium, monkeypatch):
                 z[stream] = s.precond_apply(r)
         assert np.isfinite(z["1"]).all()
         assert np.array_equal(z["0"], z["1"]), (case, precond, np.abs(z["0"] - z["1"]).max())
+
+
+@pytest.mark.parametrize("case", ["medium", "long_columns", "tracers2"])
+def test_wave_per_column_on_small_levels_is_bit_identical(case, medium, monkeypatch):
+    """Levels with few columns solve them one per WAVE (colblock_apply_kernel, factors rounded to f32 on load in the f32
+    storage mode) instead of one per lane: the same substitutions in the same order => the same bits of the whole cycle."""
+    cnt = 1
+    if case == "medium":
+        p, blk = medium
+    elif case == "long_columns":
+        p = synth.generate(imt=24, jmt=20, km=70, adv="centred", hmix="const", seed=5)
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    else:
+        p = synth.generate(imt=40, jmt=46, km=20, adv="upwind3", hmix="isop", coupled_tracer_cnt=2, seed=3)
+        cnt = 2
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, cnt)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), cnt)
+    r = np.random.default_rng(41).standard_normal(p.flat_len)
+    for f32 in ("1", "0"):
+        monkeypatch.setenv("NKP_ML_F32", f32)
+        z = {}
+        for wmax in ("0", "1000000"):
+            monkeypatch.setenv("NKP_COLWAVE_MAX", wmax)
+            with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, coupled_tracer_cnt=cnt, restart=4) as s:
+                z[wmax] = s.precond_apply(r)
+        assert np.array_equal(z["0"], z["1000000"]), (case, f32, np.abs(z["0"] - z["1000000"]).max())

@@ -47,6 +47,8 @@ ap.add_argument("--tau", type=float, default=0.01, help="geosplit: a stub is abs
 ap.add_argument("--pocket", type=int, default=0, help="geosplit: same-depth connected sets of at most this many cells become one coarse cell across groups")
 ap.add_argument("--inner", type=int, default=0, help="preconditioner = this many FGMRES steps on the twin L, each preconditioned by one cycle")
 ap.add_argument("--k33", action="store_true")
+ap.add_argument("--post-a", type=int, default=0, help="damped column-block Jacobi sweeps on A itself after the cycle")
+ap.add_argument("--post-omega", type=float, default=0.7)
 ap.add_argument("--sub", action="store_true", help="GMRES iteration counts of every sub-hierarchy and two-grid pair")
 ap.add_argument("--diagnose", type=int, default=0, help="power-iterate I - M L this many steps and describe the slow mode")
 a = ap.parse_args()
@@ -455,9 +457,21 @@ if a.sub:
     sys.exit(0)
 b = np.random.default_rng(1).standard_normal(n)
 t0 = time.time()
+if a.post_a > 0:
+    CA = A.tocoo()
+    sameA = colid0[CA.row] == colid0[CA.col]
+    BA = spla.splu(sp.csr_matrix((CA.data[sameA], (CA.row[sameA], CA.col[sameA])), shape=A.shape).tocsc(), permc_spec="NATURAL")
+
+    def prec_post(r):
+        z = cycle(levels, 0, r)
+        for _ in range(a.post_a):
+            z = z + a.post_omega * BA.solve(r - A @ z)
+        return z
 if a.inner > 0:
     Ltwin = levels[0].A
     prec = lambda r: fgmres(Ltwin, lambda q: cycle(levels, 0, q), r, 1e-30, a.inner, a.inner, verbose=False)[0]
+elif a.post_a > 0:
+    prec = prec_post
 else:
     prec = lambda r: cycle(levels, 0, r)
 x, its, rr = fgmres(A, prec, b, a.rtol, a.restart, a.maxit)
