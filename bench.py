@@ -63,6 +63,9 @@ def parse():
                     help="N = 1 extra (reported beside `value`, never as `value`): that many right-hand sides in flight at once "
                          "on clones of the solver (nkp_clone), the reference's RHS loop run concurrently; 0 disables")
     ap.add_argument("--force-dist", action="store_true", help="developer switch: run the distributed code path even with one rank")
+    ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1 collectives: rccl = the library's own RCCL communicator (C only, no Python per iteration; "
+                         "torch.distributed just carries the unique id), torch = torch.distributed callbacks")
     return ap.parse_args()
 
 
@@ -186,7 +189,7 @@ def main():
 
     def all_gather(parts, mine):
         if backend == "nccl":
-            all_gather(parts, mine)
+            dist.all_gather(parts, mine)
         else:
             hp = [q.cpu() for q in parts]
             dist.all_gather(hp, mine.cpu())
@@ -240,7 +243,8 @@ def main():
                 starts = nd.snap_partition(blk, world)
                 loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, rank, ci, cj)
                 mode = f"strong scaling: rows split into {world} latitude bands, halo alltoallv + allreduce over RCCL (torch.distributed), rank-local multilevel preconditioner"
-            comm = nd.TorchComm()
+            comm = nd.RcclComm() if (a.comm == "rccl" and backend == "nccl") else nd.TorchComm()
+            mode += f"; collectives: {'library RCCL communicator (comm_rccl.hip)' if isinstance(comm, nd.RcclComm) else 'torch.distributed callbacks'}"
             s = nd.NkpDistSolver(loc, n_global, comm, coupled_tracer_cnt=cnt_loc, **kw)
             fst = loc["fst_row"]
         except Exception as exc:                           # keep the scaling run alive, but say what happened

@@ -216,6 +216,35 @@ class TorchComm:
         return self._guard(run)
 
 
+class RcclComm:
+    """nkp_comm_ops backed by the library's own RCCL communicator (csrc/comm_rccl.hip): ncclAllReduce and grouped
+    ncclSend / ncclRecv enqueued on the solver's stream straight from C -- no Python in the per-iteration collectives.
+    torch.distributed is only used once, to hand rank 0's RCCL unique id to the other ranks."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        lib = _solver.load_library()
+        self._lib = lib
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+        self.errors = []
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0 and lib.nkp_comm_unique_id(ident) != 0:
+            raise _solver.NkpError(-5, "nkp_comm_unique_id failed")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self.ops = _solver.NkpCommOps()
+        lib.nkp_comm_rccl_init.argtypes = [C.POINTER(_solver.NkpCommOps), C.c_void_p, C.c_int, C.c_int]
+        rc = lib.nkp_comm_rccl_init(C.byref(self.ops), C.cast(ident, C.c_void_p), self.rank, self.nranks)
+        if rc != 0:
+            raise _solver.NkpError(rc, "nkp_comm_rccl_init failed")
+
+    def close(self):
+        if self.ops.ctx:
+            self._lib.nkp_comm_rccl_free.argtypes = [C.POINTER(_solver.NkpCommOps)]
+            self._lib.nkp_comm_rccl_free(C.byref(self.ops))
+
+
 class NkpDistSolver(_solver.NkpSolver):
     """nkp_create_dist: this rank's row block in, a solver for the LOCAL slices of b / x out."""
 
