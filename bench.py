@@ -220,6 +220,8 @@ def main():
                 # BASELINE configs[3]: 4 coupled tracers, tracer-major rows (src/matrix.c:778-784); the n/P rule gives a rank
                 # 4/P tracers (P <= 4) or a latitude band of one tracer (P = 8)
                 tracers_global = 4
+                if 4 % world != 0 and world % 4 != 0:
+                    raise ValueError(f"configs[3] splits 4 tracers over 1, 2, 4, 8, ... ranks, not {world} (a rank would hold parts of two tracers)")
                 p4 = synth.generate(imt=imt, jmt=jmt, km=km, adv=a.adv, hmix=a.hmix, seed=0, isop_k33=k33, coupled_tracer_cnt=4)
                 blk4 = solver.column_blocks(p4.col_start(), p4.tracer_state_len, 4)
                 ci4, cj4 = solver.column_coords(p4.ind_i, p4.ind_j, p4.col_start(), 4)

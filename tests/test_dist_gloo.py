@@ -101,3 +101,31 @@ def test_tracer_partition_exchange_over_gloo(tmp_path):
     res = launch(2, "cpu-plan", str(tmp_path / "plan_t"), extra=("--partition", "tracers"))
     assert all(r["spmv_bit_exact"] for r in res)
     assert all(r["neighbours"] == 1 and r["n_halo"] == r["m_loc"] for r in res)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config3_partition_keeps_tracers_and_columns_whole(world):
+    """bench.py's default N > 1 layout (BASELINE configs[3]: 4 coupled tracers, tracer-major rows, the reference's
+    contiguous row-block rule snapped to water columns): a rank holds whole tracers (world <= 4) or a band of ONE
+    tracer (world = 8), never a split column; the halo plan of every rank addresses the other tracers' copies of its cells."""
+    import numpy as np
+    from nk_ocn_tracer_jacobian_precond_amd import dist as nd
+    from nk_ocn_tracer_jacobian_precond_amd import solver, synth
+    p = synth.generate(imt=24, jmt=20, km=8, adv="upwind3", hmix="isop", seed=4, coupled_tracer_cnt=4)
+    tsl = p.tracer_state_len
+    blk = solver.column_blocks(p.col_start(), tsl, 4)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 4)
+    starts = nd.snap_partition(blk, world)
+    assert starts[0] == 0 and starts[-1] == p.flat_len and np.all(np.diff(starts) > 0)
+    for r in range(world):
+        loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, r, ci, cj)       # raises if a column is cut
+        f, m = loc["fst_row"], loc["m_loc"]
+        tracers = {f // tsl, (f + m - 1) // tsl}
+        if world <= 4:
+            assert f % tsl == 0 and m == (4 // world) * tsl                                # whole tracers
+        else:
+            assert len(tracers) == 1                                                       # a band of one tracer
+        ext, halo, need = nd.plan_host(loc["rowptr"], loc["colind"], starts, r)
+        own_cells = np.unique(np.arange(f, f + m) % tsl)
+        other = halo[(halo // tsl) != (f // tsl)] if world >= 4 else halo
+        assert np.isin(other % tsl, own_cells).all() or world == 8                         # same-cell couplings only (bands add lateral halo)
