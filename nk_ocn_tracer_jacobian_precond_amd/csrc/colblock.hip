@@ -435,6 +435,131 @@ void colblock_apply_lanes_kernel (const int *__restrict__ blk_start, const int *
       for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
 }
 
+// The same kernel text once more for 80-level grids (65-80 rows per column), capped at three waves per SIMD: left alone
+// the compiler spends all 256 VGPRs on hoisted factor reads and ONE wave per SIMD remains -- 0.25 degree x 80: 1120 us per
+// colour of the fine level (1 TB/s); capped it spills 56 registers of a kernel in which 8 lanes compute and runs three
+// waves per SIMD: 619 us, whole cycle 32.8 -> 24.9 ms, same bits.  The cap HURTS the 64-level kernel (3 degree: 16.1 -> 25.5
+// us) and the streamed kernel (26 -> 94 us), so it is confined to this instantiation.  (A shared __device__ body would
+// be tidier than a second copy of the text, but inlining it changed the register allocation of the other kernels.)
+template <int P, int MAXL, class FT>
+__global__ __launch_bounds__ (NKP_WAVE) __attribute__ ((amdgpu_waves_per_eu (3)))
+void colblock_apply_lanes_kernel_w3 (const int *__restrict__ blk_start, const int *__restrict__ grp_b0, const int *__restrict__ grp_nb,
+                                  const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
+                                  const FT *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
+                                  int gw, int rhs_slots, const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp)
+{
+   extern __shared__ double lds[];            // [rhs_slots] staged right-hand side | [(2P+1)*ml*gw] the group's factors
+   const int g = blockIdx.x + g_first;
+   const int lane = threadIdx.x;
+   // every index this wave needs depends on g alone: one round trip, not a chain through blk_start
+   const int nb = grp_nb[g], ml = grp_maxlen[g];
+   const int R0 = grp_row0[g], nrows = grp_row0[ngrp + g];
+   int s_pre = 0, len_pre = 0;
+   if (lane < gw) { s_pre = col_slot[g * gw + lane]; len_pre = col_slot[(ngrp + g) * gw + lane]; }
+   FT *fl = reinterpret_cast<FT *> (lds + rhs_slots);
+   // the accumulate target is requested together with the right-hand side
+   double tz[8];
+#pragma unroll
+   for (int u = 0; u < 8; u++) {
+      const int i = lane + u * NKP_WAVE;
+      tz[u] = (accumulate && i < nrows) ? z[(int64_t) R0 + i] : 0.0;
+   }
+   // bulk, fully coalesced staging: every load is independent, so the whole group is in flight at once
+   {
+      // 16-byte units of the group's factor block (ml*gw is a multiple of 64, so this is exact for f32 too)
+      const double2 *src = reinterpret_cast<const double2 *> (fac_t + grp_base[g]);
+      double2 *dst = reinterpret_cast<double2 *> (fl);
+      const int cnt2 = (int) (((size_t) (2 * P + 1) * ml * gw * sizeof (FT)) >> 4);
+      // the right-hand side and a batch of 20 factor loads per lane are all in flight before the first LDS
+      // store waits on them (a group of 8 columns x 64 levels x 5 diagonals is exactly one batch)
+      double tr[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         const int i = lane + u * NKP_WAVE;
+         tr[u] = (i < nrows) ? rhs[(int64_t) R0 + i] : 0.0;
+      }
+      constexpr int BATCH = sizeof (FT) == 4 ? 10 : 20;      // 16-byte loads per lane: one batch covers 8 x 64 x 5 factors
+      for (int i0 = lane; i0 < cnt2; i0 += BATCH * NKP_WAVE) {
+         double2 t[BATCH];
+#pragma unroll
+         for (int u = 0; u < BATCH; u++) {
+            const int i = i0 + u * NKP_WAVE;
+            t[u] = (i < cnt2) ? src[i] : make_double2 (0.0, 0.0);
+         }
+#pragma unroll
+         for (int u = 0; u < BATCH; u++) {
+            const int i = i0 + u * NKP_WAVE;
+            if (i < cnt2) dst[i] = t[u];
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         const int i = lane + u * NKP_WAVE;
+         if (i < nrows) lds[LDS_PAD (i)] = tr[u];
+      }
+   }
+   for (int i = lane + 8 * NKP_WAVE; i < nrows; i += NKP_WAVE) lds[LDS_PAD (i)] = rhs[(int64_t) R0 + i];
+   __syncthreads ();
+
+   if (lane < nb) {
+      const int s = s_pre;
+      const int len = len_pre;
+      const FT *ft = fl + lane;
+      const int dstride = ml * gw;
+      // the whole column lives in registers: no LDS write sits between two LDS reads, so the compiler
+      // can keep the (read-only) factor reads in flight ahead of the dependent arithmetic
+      double v[MAXL];
+#pragma unroll
+      for (int k = 0; k < MAXL; k++) v[k] = (k < len) ? lds[LDS_PAD (s + k)] : 0.0;
+      // forward: y_k = ((r_k - l(k,k-P) y_{k-P}) ... - l(k,k-1) y_{k-1})   (far diagonal first, like the column sweep)
+      // steps k >= len need no predicate: their factors are zero-padded, so they compute 0 - 0*x = 0;
+      // the only branch left is wave-uniform (k < ml), which keeps the LDS reads hoistable
+      // ml is a multiple of 8 (layout builder), so the only branch is one wave-uniform test per 8 steps and
+      // the 8*P factor reads of a chunk are issued together, ahead of the dependent arithmetic
+#pragma unroll
+      for (int k0 = 0; k0 < MAXL; k0 += 8) {
+         if (k0 < ml) {
+#pragma unroll
+            for (int k = k0; k < k0 + 8; k++) {
+               double y = v[k];
+#pragma unroll
+               for (int q = P; q >= 1; q--)
+                  if (k - q >= 0) y -= (double) ft[(P - q) * dstride + k * gw] * v[k - q];
+               v[k] = y;
+            }
+         }
+      }
+      // backward: x_k = (((y_k - u(k,k+P) x_{k+P}) ... - u(k,k+1) x_{k+1}) * (1/u_kk)
+#pragma unroll
+      for (int k0 = MAXL - 8; k0 >= 0; k0 -= 8) {
+         if (k0 < ml) {
+#pragma unroll
+            for (int k = k0 + 7; k >= k0; k--) {
+               double x = v[k];
+#pragma unroll
+               for (int q = P; q >= 1; q--)
+                  if (k + q < MAXL) x -= (double) ft[(P + q) * dstride + k * gw] * v[k + q];
+               x *= (double) ft[P * dstride + k * gw];
+               v[k] = x;
+            }
+         }
+      }
+#pragma unroll
+      for (int k = 0; k < MAXL; k++)
+         if (k < len) lds[LDS_PAD (s + k)] = v[k];
+   }
+   __syncthreads ();
+   if (accumulate) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         const int i = lane + u * NKP_WAVE;
+         if (i < nrows) z[(int64_t) R0 + i] = tz[u] + lds[LDS_PAD (i)];
+      }
+      for (int i = lane + 8 * NKP_WAVE; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] += lds[LDS_PAD (i)];
+   } else
+      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
+}
+
 
 // ================================================================ lane-per-column apply, 64 columns per wave, factors streamed
 // The 8-columns-per-wave kernel above keeps 56 of 64 lanes idle during the substitution and stages the factors through
@@ -637,6 +762,11 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<PP, ML, double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
       (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel<PP, ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
       LDS_OPT_IN (1, 64); LDS_OPT_IN (2, 64); LDS_OPT_IN (4, 64); LDS_OPT_IN (1, 128); LDS_OPT_IN (2, 128); LDS_OPT_IN (4, 128);
+#undef LDS_OPT_IN
+#define LDS_OPT_IN(PP, ML)                                                                                                              \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel_w3<PP, ML, double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_lanes_kernel_w3<PP, ML, float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
+      LDS_OPT_IN (1, 80); LDS_OPT_IN (2, 80); LDS_OPT_IN (4, 80);
 #undef LDS_OPT_IN
 #define LDS_OPT_IN(PP, ML)                                                                                                              \
       (void) hipFuncSetAttribute ((const void *) colblock_apply_stream_kernel<PP, ML, double, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
@@ -984,9 +1114,19 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
 #undef STREAM_LAUNCH3
       return;
    }
+   static int use_w3 = -1;
+   if (use_w3 < 0) { const char *e = getenv ("NKP_COL_W3"); use_w3 = e ? atoi (e) != 0 : 1; }
+#define LANES_LAUNCH_W3(PP, ML)                                                                                                                                 \
+   do {                                                                                                                                                        \
+      if (B.fac_tf) hipLaunchKernelGGL ((colblock_apply_lanes_kernel_w3<PP, ML, float>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.blk_start, B.grp_b0, B.grp_nb, \
+                                        B.grp_maxlen, B.grp_base, g0, B.fac_tf, r, z, accumulate, B.gw, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp);             \
+      else hipLaunchKernelGGL ((colblock_apply_lanes_kernel_w3<PP, ML, double>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.blk_start, B.grp_b0, B.grp_nb,          \
+                               B.grp_maxlen, B.grp_base, g0, B.fac_t, r, z, accumulate, B.gw, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp);                       \
+   } while (0)
 #define LANES_LAUNCH(PP)                                                                                                   \
    do {                                                                                                                    \
       if (B.max_len <= 64) LANES_LAUNCH2 (PP, 64);                                                                         \
+      else if (B.max_len <= 80 && use_w3) LANES_LAUNCH_W3 (PP, 80);                                                        \
       else LANES_LAUNCH2 (PP, 128);                                                                                        \
    } while (0)
 #define LANES_LAUNCH2(PP, ML)                                                                                                                                   \
@@ -1001,4 +1141,5 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
    else LANES_LAUNCH (4);
 #undef LANES_LAUNCH
 #undef LANES_LAUNCH2
+#undef LANES_LAUNCH_W3
 }
