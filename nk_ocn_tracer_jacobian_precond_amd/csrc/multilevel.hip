@@ -793,7 +793,12 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       if (!ok) ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l);
       if (l == 0 && !upload (&H.perm0, N.perm.data (), (size_t) nl, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
 
-      if (l < nlev - 1) {
+      static int dense_max = -1;
+      if (dense_max < 0) { const char *e = getenv ("NKP_ML_DENSE_MAX"); dense_max = e ? atoi (e) : 6000; }
+      // the last level is solved with a dense inverse when it is small enough; otherwise (rough bathymetry can leave
+      // thousands of pocket stubs that nothing absorbs) it is relaxed like the others, with many sweeps
+      const bool dense_last = (l == nlev - 1) && nl <= dense_max;
+      if (!dense_last) {
          // column blocks of this level's operator
          V.B.n = nl;
          V.B.nblk = ncol;
@@ -826,6 +831,8 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
             if (wave_max < 0) { const char *e = getenv ("NKP_COLWAVE_MAX"); wave_max = e ? atoi (e) : 8192; }
             V.wave_columns = ncol <= wave_max && V.B.dropped == 0;
          }
+      }
+      if (l < nlev - 1) {
          // transfer operators in permuted orders
          Nat &C = nat[l + 1];
          const int64_t nc = C.L.n;
@@ -842,9 +849,9 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          if (!(upload (&V.cmap, cmap_p.data (), (size_t) nl, &H.device_bytes) && upload (&V.rptr, rptr.data (), (size_t) nc + 1, &H.device_bytes) &&
                upload (&V.ridx, ridx.data (), (size_t) nl, &H.device_bytes)))
             ML_FAIL (-2, "multilevel setup: device allocation failed");
-      } else {
+      }
+      if (dense_last) {
          // coarsest level: dense inverse (permuted order)
-         if (nl > 6000) ML_FAIL (-1, "multilevel setup: coarsest level still has %lld rows; raise ml_levels", (long long) nl);
          std::vector<double> dense ((size_t) nl * nl, 0.0);
          for (int64_t i = 0; i < nl; i++)
             for (int e = prow[i]; e < prow[i + 1]; e++) dense[(size_t) i * nl + pcol[e]] = pval[e];
@@ -853,7 +860,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       }
       if (verbose)
          printf ("(%d) multilevel: level %d: %lld rows, %lld entries, %d columns (%d + %d by colour)%s\n", rank, l, (long long) nl,
-                 (long long) prow[nl], ncol, N.ncol0, ncol - N.ncol0, l == nlev - 1 ? ", dense solve" : "");
+                 (long long) prow[nl], ncol, N.ncol0, ncol - N.ncol0, l < nlev - 1 ? "" : dense_last ? ", dense solve" : ", relaxed (too large for a dense inverse)");
       t_dev += secs (t_dev0);
    }
    {
@@ -936,9 +943,19 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
    }
    MlLevel &V = H.lev[l];
    V.cur[0] = V.cur[1] = 0;
-   if (l == H.tail_from && H.gamma_to <= H.gamma_from && ml_tail_launch (H, l, st) == 0) return;
+   if (l == H.tail_from && H.coarse_inv && H.gamma_to <= H.gamma_from && ml_tail_launch (H, l, st) == 0) return;
    if (l == (int) H.lev.size () - 1) {
-      launch_dense_matvec (H.coarse_inv, V.b, V.x, (int) V.n, st);
+      if (H.coarse_inv) {
+         launch_dense_matvec (H.coarse_inv, V.b, V.x, (int) V.n, st);
+         return;
+      }
+      // no dense inverse: many sweeps of the column smoother from x = 0 (what is left here is diagonally dominant)
+      static int sweeps = -1;
+      if (sweeps < 0) { const char *e = getenv ("NKP_ML_COARSEST_SWEEPS"); sweeps = (e && atoi (e) > 0) ? atoi (e) : 30; }
+      launch_fill (V.x, 0.0, V.n, st);
+      column_solves (H, V, 0, V.b, V.x, 0, st);
+      gs_half (H, V, 1, false, st);
+      for (int s = 1; s < sweeps; s++) gs_sweep (H, V, s & 1, false, st);
       return;
    }
    const bool fused = H.fused && V.B.gs_ok;

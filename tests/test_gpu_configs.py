@@ -59,3 +59,14 @@ def test_config_quarter_degree():
     info = _solve(p, restart=60)
     assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
     assert info["iters"] <= 400, info
+
+
+def test_coarsest_level_without_dense_inverse(monkeypatch):
+    """Rough bathymetry can leave a coarsest level too large for the dense inverse (thousands of pocket stubs): it is then
+    relaxed with many sweeps of the column smoother instead of failing the setup.  Forced here by lowering the limit."""
+    p = synth.generate(imt=100, jmt=116, km=60, adv="upwind3", hmix="isop", seed=0)
+    ref = _solve(p)
+    monkeypatch.setenv("NKP_ML_DENSE_MAX", "50")
+    info = _solve(p)
+    assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
+    assert info["iters"] <= 2 * ref["iters"] + 10, (info, ref)
