@@ -30,6 +30,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <array>
 #include <chrono>
 #include <numeric>
@@ -242,11 +244,37 @@ struct SplitResult {
    int absorbed = 0, stubs = 0;
 };
 
+// Lock-free union-find (several host threads unite concurrently): a root is only ever linked under a LOWER index with a
+// compare-and-swap, so the final root of every set is its lowest row whatever the interleaving -- the partition and the
+// numbering derived from it are deterministic.
 struct UnionFind {
-   std::vector<int> p;
-   explicit UnionFind (size_t n) : p (n) { std::iota (p.begin (), p.end (), 0); }
-   int find (int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
-   void unite (int a, int b) { a = find (a); b = find (b); if (a != b) { if (a < b) p[b] = a; else p[a] = b; } }   // root = lowest row
+   std::unique_ptr<std::atomic<int>[]> p;
+   size_t n;
+   explicit UnionFind (size_t n_) : p (n_ ? new std::atomic<int>[n_] : nullptr), n (n_)
+   {
+      for (size_t i = 0; i < n; i++) p[i].store ((int) i, std::memory_order_relaxed);
+   }
+   int find (int x)
+   {
+      for (;;) {
+         const int px = p[x].load (std::memory_order_relaxed);
+         if (px == x) return x;
+         const int gp = p[px].load (std::memory_order_relaxed);
+         if (gp != px) { int expect = px; p[x].compare_exchange_weak (expect, gp, std::memory_order_relaxed); }   // path halving
+         x = px;
+      }
+   }
+   void unite (int a, int b)
+   {
+      for (;;) {
+         a = find (a);
+         b = find (b);
+         if (a == b) return;
+         if (a > b) std::swap (a, b);                              // link the higher root b under the lower root a
+         int expect = b;
+         if (p[b].compare_exchange_strong (expect, a, std::memory_order_relaxed)) return;
+      }
+   }
 };
 
 void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const std::vector<int> &col_of, const std::vector<int> &ktop,
@@ -255,6 +283,14 @@ void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const
 {
    const int64_t n = L.n;
    const int ncol = (int) blk_start.size () - 1;
+   const bool timing = getenv ("NKP_ML_PLAN_TIMES") != nullptr;
+   auto tick0 = std::chrono::steady_clock::now ();
+   auto lap = [&] (const char *what) {
+      if (!timing) return;
+      auto now = std::chrono::steady_clock::now ();
+      printf ("   split_aggregate (%lld rows): %-28s %.3f s\n", (long long) n, what, std::chrono::duration<double> (now - tick0).count ());
+      tick0 = now;
+   };
    auto depth = [&] (int r) { const int c = col_of[r]; return ktop[c] + (r - blk_start[c]); };
    auto row_at = [&] (int c, int k) -> int { const int r = blk_start[c] + (k - ktop[c]); return (k >= ktop[c] && r < blk_start[c + 1]) ? r : -1; };
    // per row: strongest lateral coupling (only needed for a threshold theta > 0); per column: how strongly any outside
@@ -296,6 +332,7 @@ void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const
       for (int c = 0; c < ncol; c++) bad[c] = dang[c] && dang[col_of[anchor[c]]];
       for (int c = 0; c < ncol; c++) if (bad[c]) dang[c] = 0;
    }
+   lap ("stub analysis");
    // lateral edges between cells of the same depth, united on the fly: U0 over all of them (it finds the small same-depth
    // sets = pockets), U over the edges inside a group; a second scan of the pockets' rows adds their cross-group edges to U
    UnionFind U (n), U0 (pocket > 0 ? n : 0);
@@ -313,18 +350,24 @@ void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const
          if (t >= 0) visit ((int) r, t, group[c] == group[c2]);
       }
    };
-   for (int64_t r = 0; r < n; r++)
-      scan_row (r, [&] (int a, int b, bool same) {
-         if (pocket > 0) U0.unite (a, b);
-         if (same) U.unite (a, b);
-      });
+   for_row_chunks (n, [&] (int, int64_t r0, int64_t r1) {
+      for (int64_t r = r0; r < r1; r++)
+         scan_row (r, [&] (int a, int b, bool same) {
+            if (pocket > 0) U0.unite (a, b);
+            if (same) U.unite (a, b);
+         });
+   });
    if (pocket > 0) {
-      std::vector<int> size (n, 0);
-      for (int64_t r = 0; r < n; r++) size[U0.find ((int) r)]++;
-      for (int64_t r = 0; r < n; r++)
-         if (size[U0.find ((int) r)] <= pocket && size[U0.find ((int) r)] > 1)
-            scan_row (r, [&] (int a, int b, bool same) { if (!same) U.unite (a, b); });
+      std::vector<int> root0 (n), size (n, 0);
+      for_row_chunks (n, [&] (int, int64_t r0, int64_t r1) { for (int64_t r = r0; r < r1; r++) root0[r] = U0.find ((int) r); });
+      for (int64_t r = 0; r < n; r++) size[root0[r]]++;
+      for_row_chunks (n, [&] (int, int64_t r0, int64_t r1) {
+         for (int64_t r = r0; r < r1; r++)
+            if (size[root0[r]] <= pocket && size[root0[r]] > 1)
+               scan_row (r, [&] (int a, int b, bool same) { if (!same) U.unite (a, b); });
+      });
    }
+   lap ("union-find over the edges");
    // components numbered in order of their lowest row
    std::vector<int> comp (n, -1);
    int ncomp = 0;
@@ -335,26 +378,48 @@ void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const
    }
    std::vector<int> kcomp (ncomp, 0);
    for (int64_t r = 0; r < n; r++) kcomp[comp[r]] = depth ((int) r);
-   // overlaps between a set and the sets directly below it
-   std::vector<std::pair<int, int>> pc;
-   pc.reserve (n);
-   for (int c = 0; c < ncol; c++)
-      for (int r = blk_start[c]; r + 1 < blk_start[c + 1]; r++) pc.emplace_back (comp[r], comp[r + 1]);
-   std::sort (pc.begin (), pc.end ());
+   lap ("component numbering");
+   // overlaps between a set and the sets directly below it: the pairs (set of row r, set of the row below r) are bucketed
+   // by parent with a counting sort (set ids are dense), every bucket -- the handful of rows of one set -- is sorted and
+   // its runs counted
    std::vector<int> bestpar (ncomp, -1), bestpar_cnt (ncomp, 0), bestchi (ncomp, -1), bestchi_cnt (ncomp, 0);
-   for (size_t q = 0; q < pc.size ();) {
-      size_t q2 = q;
-      while (q2 < pc.size () && pc[q2] == pc[q]) q2++;
-      const int par = pc[q].first, chi = pc[q].second, cnt = (int) (q2 - q);
-      // pairs arrive sorted by (parent, child): a strict '>' keeps the lowest id on ties
-      if (cnt > bestpar_cnt[chi]) { bestpar_cnt[chi] = cnt; bestpar[chi] = par; }
-      if (cnt > bestchi_cnt[par]) { bestchi_cnt[par] = cnt; bestchi[par] = chi; }
-      q = q2;
+   {
+      std::vector<int> bptr ((size_t) ncomp + 1, 0);
+      for (int c = 0; c < ncol; c++)
+         for (int r = blk_start[c]; r + 1 < blk_start[c + 1]; r++) bptr[(size_t) comp[r] + 1]++;
+      for (int q = 0; q < ncomp; q++) bptr[(size_t) q + 1] += bptr[(size_t) q];
+      std::vector<int> child ((size_t) bptr[(size_t) ncomp]);
+      {
+         std::vector<int> fill (bptr.begin (), bptr.end () - 1);
+         for (int c = 0; c < ncol; c++)
+            for (int r = blk_start[c]; r + 1 < blk_start[c + 1]; r++) child[(size_t) fill[(size_t) comp[r]]++] = comp[r + 1];
+      }
+      // parents in ascending id, children ascending inside a bucket: a strict '>' keeps the lowest id on ties, like the
+      // sorted list of pairs did
+      for (int par = 0; par < ncomp; par++) {
+         int *b0 = child.data () + bptr[(size_t) par], *b1 = child.data () + bptr[(size_t) par + 1];
+         if (b1 - b0 > 1) std::sort (b0, b1);
+         for (int *q = b0; q < b1;) {
+            int *q2 = q;
+            while (q2 < b1 && *q2 == *q) q2++;
+            const int chi = *q, cnt = (int) (q2 - q);
+            if (cnt > bestpar_cnt[chi]) { bestpar_cnt[chi] = cnt; bestpar[chi] = par; }
+            if (cnt > bestchi_cnt[par]) { bestchi_cnt[par] = cnt; bestchi[par] = chi; }
+            q = q2;
+         }
+      }
    }
-   // coarse columns: sets in order of depth, then of id
+   lap ("overlap pairs (buckets)");
+   // coarse columns: sets in order of depth (counting sort), then of id
    std::vector<int> order (ncomp);
-   std::iota (order.begin (), order.end (), 0);
-   std::stable_sort (order.begin (), order.end (), [&] (int a, int b) { return kcomp[a] < kcomp[b]; });
+   {
+      int kmax = 0;
+      for (int q = 0; q < ncomp; q++) kmax = std::max (kmax, kcomp[q]);
+      std::vector<int> kptr ((size_t) kmax + 2, 0);
+      for (int q = 0; q < ncomp; q++) kptr[(size_t) kcomp[q] + 1]++;
+      for (int k = 0; k <= kmax; k++) kptr[(size_t) k + 1] += kptr[(size_t) k];
+      for (int q = 0; q < ncomp; q++) order[(size_t) kptr[(size_t) kcomp[q]]++] = q;
+   }
    std::vector<int> ccol (ncomp, -1), cc_ktop, cc_len;
    for (int id : order) {
       const int par = bestpar[id];
@@ -367,6 +432,7 @@ void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const
          cc_len.push_back (1);
       }
    }
+   lap ("threading");
    // absorbed stubs own no coarse column: drop the (now empty) columns their sets opened
    const int nraw = (int) cc_ktop.size ();
    // a coarse column sits at the (i, j) of the group of its lowest fine row (a merged pocket can span groups)
@@ -394,6 +460,7 @@ void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const
       const int a = newid[ccol[comp[r]]];
       R.cmap[r] = R.blk_start[a] + (depth ((int) r) - R.ktop[a]);
    }
+   lap ("coarse columns and map");
    for (int c = 0; c < ncol; c++) {
       if (!dang[c]) continue;
       R.absorbed++;
@@ -413,35 +480,55 @@ void galerkin (const HostCsr &L, const std::vector<int> &cmap, int64_t nc, HostC
       std::vector<int> fill (rptr.begin (), rptr.end () - 1);
       for (int64_t i = 0; i < L.n; i++) ridx[fill[cmap[i]]++] = (int) i;
    }
+   // coarse rows in parallel: every thread owns a contiguous run of coarse rows, with its own accumulator over the
+   // coarse columns, and appends to its own output; the pieces are stitched together in row order
    C.n = nc;
    C.rowptr.assign (nc + 1, 0);
-   C.colind.clear ();
-   C.val.clear ();
-   C.colind.reserve (L.colind.size () / 2);
-   C.val.reserve (L.colind.size () / 2);
-   std::vector<double> acc (nc, 0.0);
-   std::vector<char> mark (nc, 0);
-   std::vector<int> touched;
-   for (int64_t I = 0; I < nc; I++) {
-      touched.clear ();
-      for (int q = rptr[I]; q < rptr[I + 1]; q++) {
-         const int i = ridx[q];
-         for (int e = L.rowptr[i]; e < L.rowptr[i + 1]; e++) {
-            const int J = cmap[L.colind[e]];
-            if (!mark[J]) { mark[J] = 1; touched.push_back (J); }
-            acc[J] += L.val[e];
+   const int nt_max = setup_threads ();
+   std::vector<std::vector<int>> pc (nt_max);
+   std::vector<std::vector<double>> pv (nt_max);
+   std::vector<int64_t> first (nt_max, 0), last (nt_max, 0);
+   for_row_chunks (nc, [&] (int t, int64_t I0, int64_t I1) {
+      first[t] = I0;
+      last[t] = I1;
+      std::vector<double> acc (nc, 0.0);
+      std::vector<char> mark (nc, 0);
+      std::vector<int> touched;
+      std::vector<int> &oc = pc[t];
+      std::vector<double> &ov = pv[t];
+      oc.reserve ((size_t) ((L.colind.size () / 2) * (double) (I1 - I0) / (double) (nc ? nc : 1)) + 16);
+      ov.reserve (oc.capacity ());
+      for (int64_t I = I0; I < I1; I++) {
+         touched.clear ();
+         for (int q = rptr[I]; q < rptr[I + 1]; q++) {
+            const int i = ridx[q];
+            for (int e = L.rowptr[i]; e < L.rowptr[i + 1]; e++) {
+               const int J = cmap[L.colind[e]];
+               if (!mark[J]) { mark[J] = 1; touched.push_back (J); }
+               acc[J] += L.val[e];
+            }
          }
-      }
-      std::sort (touched.begin (), touched.end ());
-      for (int J : touched) {
-         if (acc[J] != 0.0 || J == I) {
-            C.colind.push_back (J);
-            C.val.push_back (acc[J]);
+         std::sort (touched.begin (), touched.end ());
+         int cnt = 0;
+         for (int J : touched) {
+            if (acc[J] != 0.0 || J == I) {
+               oc.push_back (J);
+               ov.push_back (acc[J]);
+               cnt++;
+            }
+            acc[J] = 0.0;
+            mark[J] = 0;
          }
-         acc[J] = 0.0;
-         mark[J] = 0;
+         C.rowptr[I + 1] = cnt;
       }
-      C.rowptr[I + 1] = (int) C.colind.size ();
+   });
+   for (int64_t I = 0; I < nc; I++) C.rowptr[I + 1] += C.rowptr[I];
+   C.colind.resize ((size_t) C.rowptr[nc]);
+   C.val.resize ((size_t) C.rowptr[nc]);
+   for (int t = 0; t < nt_max; t++) {
+      if (last[t] <= first[t]) continue;
+      std::copy (pc[t].begin (), pc[t].end (), C.colind.begin () + C.rowptr[first[t]]);
+      std::copy (pv[t].begin (), pv[t].end (), C.val.begin () + C.rowptr[first[t]]);
    }
 }
 
@@ -472,6 +559,107 @@ bool dense_inverse (int n, std::vector<double> &a /* row-major n*n, overwritten 
       }
    }
    a.swap (inv);
+   return true;
+}
+
+
+// ---------------------------------------------------------------- dense inverse on the device (coarsest level)
+// Gauss-Jordan with partial pivoting, one elimination step = four small launches; the same operations as the host routine
+// above (swap, scale the pivot row by the reciprocal, subtract f x pivot row from every other row), every element updated
+// by one multiply and one subtract, so the result has the same bits -- and a 1450-row inverse takes 40 ms instead of the
+// second it cost on the host (a third of the whole 1 degree setup).
+__global__ void gj_pivot_kernel (const double *__restrict__ a, int n, int k, int *__restrict__ piv, double *__restrict__ pivval)
+{
+   __shared__ double smax[256];
+   __shared__ int sidx[256];
+   double mx = -1.0;
+   int p = k;
+   for (int i = k + (int) threadIdx.x; i < n; i += 256) {
+      const double v = fabs (a[(size_t) i * n + k]);
+      if (v > mx) { mx = v; p = i; }               // ascending i per thread: the first maximum wins
+   }
+   smax[threadIdx.x] = mx;
+   sidx[threadIdx.x] = p;
+   __syncthreads ();
+   for (int off = 128; off > 0; off >>= 1) {
+      if ((int) threadIdx.x < off) {
+         const double o = smax[threadIdx.x + off];
+         const int oi = sidx[threadIdx.x + off];
+         if (o > smax[threadIdx.x] || (o == smax[threadIdx.x] && oi < sidx[threadIdx.x])) { smax[threadIdx.x] = o; sidx[threadIdx.x] = oi; }
+      }
+      __syncthreads ();
+   }
+   if (threadIdx.x == 0) {
+      piv[0] = sidx[0];
+      if (!(smax[0] > 0.0)) piv[1] = 1;            // singular
+      pivval[0] = a[(size_t) sidx[0] * n + k];
+   }
+}
+
+__global__ void gj_swap_scale_kernel (double *__restrict__ a, double *__restrict__ inv, int n, int k, const int *__restrict__ piv, const double *__restrict__ pivval)
+{
+   const int c = blockIdx.x * 256 + threadIdx.x;
+   if (c >= n) return;
+   const int p = piv[0];
+   const double r = 1.0 / pivval[0];
+   double *m[2] = { a, inv };
+   for (int w = 0; w < 2; w++) {
+      const double vk = m[w][(size_t) k * n + c], vp = m[w][(size_t) p * n + c];
+      m[w][(size_t) k * n + c] = vp * r;
+      if (p != k) m[w][(size_t) p * n + c] = vk;
+   }
+}
+
+__global__ void gj_column_kernel (const double *__restrict__ a, int n, int k, double *__restrict__ fcol)
+{
+   const int i = blockIdx.x * 256 + threadIdx.x;
+   if (i < n) fcol[i] = a[(size_t) i * n + k];
+}
+
+__global__ void gj_update_kernel (double *__restrict__ a, double *__restrict__ inv, int n, int k, const double *__restrict__ fcol)
+{
+   const int i = blockIdx.y;
+   const int c = blockIdx.x * 256 + threadIdx.x;
+   if (c >= n || i == k) return;
+   const double f = fcol[i];
+   if (f == 0.0) return;
+   a[(size_t) i * n + c] -= f * a[(size_t) k * n + c];
+   inv[(size_t) i * n + c] -= f * inv[(size_t) k * n + c];
+}
+
+// a (device, row-major n x n) is destroyed, *inv_out receives a device buffer with the inverse; false if singular / no memory
+bool dense_inverse_device (int n, const std::vector<double> &host_a, double **inv_out, size_t *bytes, hipStream_t st)
+{
+   double *a = nullptr, *inv = nullptr, *fcol = nullptr, *pivval = nullptr;
+   int *piv = nullptr;
+   const size_t nn = (size_t) n * n;
+   bool ok = hipMalloc ((void **) &a, nn * sizeof (double)) == hipSuccess && hipMalloc ((void **) &inv, nn * sizeof (double)) == hipSuccess &&
+             hipMalloc ((void **) &fcol, (size_t) n * sizeof (double)) == hipSuccess && hipMalloc ((void **) &pivval, sizeof (double)) == hipSuccess &&
+             hipMalloc ((void **) &piv, 2 * sizeof (int)) == hipSuccess;
+   if (ok) {
+      std::vector<double> eye (nn, 0.0);
+      for (int i = 0; i < n; i++) eye[(size_t) i * n + i] = 1.0;
+      ok = hipMemcpy (a, host_a.data (), nn * sizeof (double), hipMemcpyHostToDevice) == hipSuccess &&
+           hipMemcpy (inv, eye.data (), nn * sizeof (double), hipMemcpyHostToDevice) == hipSuccess && hipMemset (piv, 0, 2 * sizeof (int)) == hipSuccess;
+   }
+   if (ok) {
+      const int cb = (n + 255) / 256;
+      for (int k = 0; k < n; k++) {
+         hipLaunchKernelGGL (gj_pivot_kernel, dim3 (1), dim3 (256), 0, st, a, n, k, piv, pivval);
+         hipLaunchKernelGGL (gj_swap_scale_kernel, dim3 (cb), dim3 (256), 0, st, a, inv, n, k, piv, pivval);
+         hipLaunchKernelGGL (gj_column_kernel, dim3 (cb), dim3 (256), 0, st, a, n, k, fcol);
+         hipLaunchKernelGGL (gj_update_kernel, dim3 (cb, n), dim3 (256), 0, st, a, inv, n, k, fcol);
+      }
+      int flags[2] = { 0, 0 };
+      ok = hipMemcpyAsync (flags, piv, sizeof flags, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize (st) == hipSuccess && flags[1] == 0;
+   }
+   if (a) (void) hipFree (a);
+   if (fcol) (void) hipFree (fcol);
+   if (pivval) (void) hipFree (pivval);
+   if (piv) (void) hipFree (piv);
+   if (!ok) { if (inv) (void) hipFree (inv); return false; }
+   *inv_out = inv;
+   *bytes += nn * sizeof (double);
    return true;
 }
 
@@ -696,6 +884,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
    using clk = std::chrono::steady_clock;
    auto secs = [] (clk::time_point a) { return std::chrono::duration<double> (clk::now () - a).count (); };
    double t_low = 0.0, t_graph = 0.0, t_galerkin = 0.0, t_perm = 0.0, t_dev = 0.0;
+   double t_rb = 0.0, t_up = 0.0, t_fac = 0.0, t_lay = 0.0, t_map = 0.0;      // pieces of t_dev
    H.nu = nu < 1 ? 1 : nu;
    H.f32 = 1;                                     // level operators and factors stored in f32, arithmetic in f64
    if (const char *e = getenv ("NKP_ML_F32")) H.f32 = atoi (e) != 0;
@@ -758,6 +947,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       V.rows0 = rows0;
       // row blocks per colour (must not straddle the colour boundary)
       int *rb0 = nullptr, *rb1 = nullptr, nrb0 = 0, nrb1 = 0;
+      auto t_rb0 = clk::now ();
       build_rowblocks_host (rows0, prow.data (), &rb0, &nrb0);
       {
          std::vector<int> shifted (nl - rows0 + 1);
@@ -777,6 +967,8 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       V.L.n = nl;
       V.L.nnz = prow[nl];
       V.L.nrowblk = nrb0 + nrb1;
+      t_rb += secs (t_rb0);
+      auto t_up0 = clk::now ();
       bool ok = upload (&V.L.rowptr, prow.data (), (size_t) nl + 1, &H.device_bytes) &&
                 upload_padded (&V.L.colind, pcol.data (), (size_t) prow[nl], 2, &H.device_bytes) &&
                 upload_padded (&V.L.val, pval.data (), (size_t) prow[nl], 2, &H.device_bytes) &&
@@ -790,6 +982,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          std::vector<float> vf (pval.begin (), pval.begin () + prow[nl]);
          ok = upload_padded (&V.L.valf, vf.data (), vf.size (), 2, &H.device_bytes);
       }
+      t_up += secs (t_up0);
       if (!ok) ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l);
       if (l == 0 && !upload (&H.perm0, N.perm.data (), (size_t) nl, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
 
@@ -806,6 +999,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          int *dint = nullptr;
          size_t dummy = 0;
          std::vector<int> zeros (8, 0);
+         auto t_fac0 = clk::now ();
          if (!upload (&dint, zeros.data (), 8, &dummy)) ML_FAIL (-2, "multilevel setup: device allocation failed");
          launch_colblock_measure (V.L, V.B, dint, st);
          int meas[3];
@@ -823,17 +1017,21 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          (void) hipFree (dint);
          if (st2[0] != 0) ML_FAIL (-4, "multilevel setup: zero pivot in a column block of level %d (row %d)", l, st2[0] - 1);
          V.B.dropped = st2[1];
+         t_fac += secs (t_fac0);
          {
+            auto t_lay0 = clk::now ();
             const int ranges[3] = { 0, N.ncol0, ncol };
             const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st, H.f32, H.fused ? prow.data () : nullptr);
             if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
             static int wave_max = -1;
             if (wave_max < 0) { const char *e = getenv ("NKP_COLWAVE_MAX"); wave_max = e ? atoi (e) : 8192; }
             V.wave_columns = ncol <= wave_max && V.B.dropped == 0;
+            t_lay += secs (t_lay0);
          }
       }
       if (l < nlev - 1) {
          // transfer operators in permuted orders
+         auto t_map0 = clk::now ();
          Nat &C = nat[l + 1];
          const int64_t nc = C.L.n;
          V.nc = nc;
@@ -849,14 +1047,20 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
          if (!(upload (&V.cmap, cmap_p.data (), (size_t) nl, &H.device_bytes) && upload (&V.rptr, rptr.data (), (size_t) nc + 1, &H.device_bytes) &&
                upload (&V.ridx, ridx.data (), (size_t) nl, &H.device_bytes)))
             ML_FAIL (-2, "multilevel setup: device allocation failed");
+         t_map += secs (t_map0);
       }
       if (dense_last) {
          // coarsest level: dense inverse (permuted order)
          std::vector<double> dense ((size_t) nl * nl, 0.0);
          for (int64_t i = 0; i < nl; i++)
             for (int e = prow[i]; e < prow[i + 1]; e++) dense[(size_t) i * nl + pcol[e]] = pval[e];
-         if (!dense_inverse ((int) nl, dense)) ML_FAIL (-4, "multilevel setup: coarsest operator is singular");
-         if (!upload (&H.coarse_inv, dense.data (), dense.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+         static int host_inverse = -1;
+         if (host_inverse < 0) { const char *e = getenv ("NKP_ML_HOST_INVERSE"); host_inverse = e ? atoi (e) != 0 : 0; }
+         if (host_inverse) {
+            if (!dense_inverse ((int) nl, dense)) ML_FAIL (-4, "multilevel setup: coarsest operator is singular");
+            if (!upload (&H.coarse_inv, dense.data (), dense.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+         } else if (!dense_inverse_device ((int) nl, dense, &H.coarse_inv, &H.device_bytes, st))
+            ML_FAIL (-4, "multilevel setup: coarsest operator is singular (or the device is out of memory)");
       }
       if (verbose)
          printf ("(%d) multilevel: level %d: %lld rows, %lld entries, %d columns (%d + %d by colour)%s\n", rank, l, (long long) nl,
@@ -878,7 +1082,8 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
    }
    if (verbose) {
       printf ("(%d) multilevel setup: %.2f s low-order twin, %.2f s column graphs, %.2f s Galerkin products, %.2f s colour-major permutation, "
-              "%.2f s uploads + factorisation + lane layouts\n", rank, t_low, t_graph, t_galerkin, t_perm, t_dev);
+              "%.2f s uploads + factorisation + lane layouts (row blocks %.2f, operator uploads %.2f, column factors %.2f, lane layouts %.2f, transfer maps %.2f)\n",
+              rank, t_low, t_graph, t_galerkin, t_perm, t_dev, t_rb, t_up, t_fac, t_lay, t_map);
       fflush (stdout);
    }
    return 0;

@@ -16,9 +16,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 static thread_local std::string g_last_error;
@@ -244,21 +246,41 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    if (opt.restart > NKP_MAX_K - 2) opt.restart = NKP_MAX_K - 2;
    if (opt.precond != NKP_PRECOND_NONE && opt.precond != NKP_PRECOND_COLUMN_JACOBI && opt.precond != NKP_PRECOND_MULTILEVEL)
       return fail (NKP_EINVAL, "nkp_create: unknown preconditioner %d", opt.precond);
-   // host-side validation of what the kernels will trust
-   for (int64_t r = 0; r < n; r++) {
-      if (rowptr[r + 1] < rowptr[r]) return fail (NKP_EINVAL, "nkp_create: rowptr decreases at row %lld", (long long) r);
-      for (int e = rowptr[r]; e < rowptr[r + 1]; e++)
-         if (colind[e] < 0 || colind[e] >= n) return fail (NKP_EINVAL, "nkp_create: column index %d out of range in row %lld", colind[e], (long long) r);
-      if (opt.precond != NKP_PRECOND_NONE) {
-         bool have_diag = false;
-         for (int e = rowptr[r]; e < rowptr[r + 1]; e++)
-            if (colind[e] == r && val[e] != 0.0) have_diag = true;
-         if (!have_diag)
-            return fail (NKP_ESINGULAR, "nkp_create: row %lld has no (or a zero) diagonal entry; the water-column preconditioners need one (the reference only reports this: src/matrix.c:3692-3727)", (long long) r);
+   // host-side validation of what the kernels will trust (row chunks in parallel; the lowest offending row is reported)
+   {
+      struct Bad { int64_t row = -1; int kind = 0; int col = 0; };
+      const int nt = (n >= 200000) ? (int) std::min (16u, std::max (1u, std::thread::hardware_concurrency ())) : 1;
+      std::vector<Bad> bad ((size_t) nt);
+      auto check = [&] (int t) {
+         const int64_t r0 = n * t / nt, r1 = n * (t + 1) / nt;
+         for (int64_t r = r0; r < r1 && bad[(size_t) t].row < 0; r++) {
+            Bad b;
+            if (rowptr[r + 1] < rowptr[r]) b.kind = 1;
+            else {
+               bool have_diag = false;
+               for (int e = rowptr[r]; e < rowptr[r + 1] && !b.kind; e++) {
+                  if (colind[e] < 0 || colind[e] >= n) { b.kind = 2; b.col = colind[e]; }
+                  else if (colind[e] == r && val[e] != 0.0) have_diag = true;
+                  else if (opt.precond == NKP_PRECOND_MULTILEVEL && e > rowptr[r] && colind[e] <= colind[e - 1]) b.kind = 4;
+               }
+               if (!b.kind && opt.precond != NKP_PRECOND_NONE && !have_diag) b.kind = 3;
+            }
+            if (b.kind) { b.row = r; bad[(size_t) t] = b; }
+         }
+      };
+      if (nt == 1) check (0);
+      else {
+         std::vector<std::thread> pool;
+         for (int t = 0; t < nt; t++) pool.emplace_back (check, t);
+         for (std::thread &th : pool) th.join ();
       }
-      if (opt.precond == NKP_PRECOND_MULTILEVEL)
-         for (int e = rowptr[r] + 1; e < rowptr[r + 1]; e++)
-            if (colind[e] <= colind[e - 1]) return fail (NKP_EINVAL, "nkp_create: row %lld is not sorted by column (the multilevel setup needs the sorted rows gen_A writes)", (long long) r);
+      for (const Bad &b : bad) {
+         if (b.row < 0) continue;
+         if (b.kind == 1) return fail (NKP_EINVAL, "nkp_create: rowptr decreases at row %lld", (long long) b.row);
+         if (b.kind == 2) return fail (NKP_EINVAL, "nkp_create: column index %d out of range in row %lld", b.col, (long long) b.row);
+         if (b.kind == 3) return fail (NKP_ESINGULAR, "nkp_create: row %lld has no (or a zero) diagonal entry; the water-column preconditioners need one (the reference only reports this: src/matrix.c:3692-3727)", (long long) b.row);
+         return fail (NKP_EINVAL, "nkp_create: row %lld is not sorted by column (the multilevel setup needs the sorted rows gen_A writes)", (long long) b.row);
+      }
    }
    std::vector<int> blk_default;
    if (opt.precond != NKP_PRECOND_NONE) {
@@ -291,6 +313,9 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
          msg (s, 1, "warning: device %d is %s, kernels are built and tuned for gfx950\n", s->device, prop.gcnArchName);
    }
    int rc = NKP_OK;
+   struct timespec ts0_;
+   clock_gettime (CLOCK_MONOTONIC, &ts0_);
+   auto since0 = [&] () { struct timespec t; clock_gettime (CLOCK_MONOTONIC, &t); return (double) (t.tv_sec - ts0_.tv_sec) + 1e-9 * (double) (t.tv_nsec - ts0_.tv_nsec); };
 #define TRY(x) do { rc = (x); if (rc != NKP_OK) { solver_free (s); return rc; } } while (0)
 #define TRYHIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = fail (NKP_EDEVICE, "%s failed: %s", #call, hipGetErrorString (e_)); solver_free (s); return rc; } } while (0)
    TRYHIP (hipStreamCreateWithFlags (&s->stream, hipStreamNonBlocking));
@@ -351,6 +376,7 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
       TRYHIP (hipMemcpy (s->rinv, ri.data (), (size_t) n * sizeof (double), hipMemcpyHostToDevice));
    }
 
+   const double t_matrix = since0 ();
    // work space
    const int m = s->m;
    TRY (dev_alloc (s, &s->V, (size_t) s->ld * (size_t) (m + 1)));
@@ -374,6 +400,7 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    TRYHIP (hipHostMalloc ((void **) &s->hpin, (size_t) (m + 16) * sizeof (double), hipHostMallocDefault));
    TRYHIP (hipMemset (s->dscal, 0, (size_t) (3 * (m + 2) + 16 + 8) * sizeof (double)));
 
+   const double t_work = since0 ();
    if (opt.precond == NKP_PRECOND_MULTILEVEL) {
       char err[256] = "";
       // developer switch: build the hierarchy without the couplings between tracers, i.e. exactly the
@@ -446,8 +473,8 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    }
    TRYHIP (hipStreamSynchronize (s->stream));
    TRYHIP (hipGetLastError ());
-   msg (s, 1, "nkp_create: n = %lld, nnz = %lld, %d SpMV row blocks, %.1f MB on device %d\n", (long long) n, (long long) M.nnz,
-        s->A.nrowblk, (double) s->device_bytes / 1.0e6, s->device);
+   msg (s, 1, "nkp_create: n = %lld, nnz = %lld, %d SpMV row blocks, %.1f MB on device %d; %.2f s matrix upload + row blocks, %.2f s work vectors, %.2f s preconditioner\n",
+        (long long) n, (long long) M.nnz, s->A.nrowblk, (double) s->device_bytes / 1.0e6, s->device, t_matrix, t_work - t_matrix, since0 () - t_work);
    *out = s;
    return NKP_OK;
 #undef TRY

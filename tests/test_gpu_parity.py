@@ -695,3 +695,17 @@ def test_wave_per_column_on_small_levels_is_bit_identical(case, medium, monkeypa
             with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, coupled_tracer_cnt=cnt, restart=4) as s:
                 z[wmax] = s.precond_apply(r)
         assert np.array_equal(z["0"], z["1000000"]), (case, f32, np.abs(z["0"] - z["1000000"]).max())
+
+
+def test_device_dense_inverse_matches_host(medium, monkeypatch):
+    """The coarsest level's dense inverse is computed on the device (Gauss-Jordan, four small launches per step) with the
+    host routine's operations: the cycle must not change by a bit."""
+    p, blk = medium
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    r = np.random.default_rng(43).standard_normal(p.flat_len)
+    z = {}
+    for host in ("1", "0"):
+        monkeypatch.setenv("NKP_ML_HOST_INVERSE", host)
+        with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, restart=4) as s:
+            z[host] = s.precond_apply(r)
+    assert np.array_equal(z["0"], z["1"]), np.abs(z["0"] - z["1"]).max()
