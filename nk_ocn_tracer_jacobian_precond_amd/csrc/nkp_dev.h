@@ -36,6 +36,8 @@ int attach_spmv_codes (CsrDev &A, const int *h_rowptr, const int *h_colind, cons
 void launch_csr_spmv (const CsrDev &A, const double *x, double *y, const double *b, int mode, hipStream_t st);
 // rows of the row blocks [rb0, rb1) only: y_rows = b_rows - (A x)_rows  (Gauss-Seidel colour sweep)
 void launch_csr_residual_range (const CsrDev &A, int rb0, int rb1, const double *x, const double *b, double *y, hipStream_t st);
+// rows of the row blocks [rb0, rb1) only, any mode (0: y = A x, 1: y = b - A x, 2: y = |A||x| + |b|)
+void launch_csr_spmv_range (const CsrDev &A, int rb0, int rb1, const double *x, double *y, const double *b, int mode, hipStream_t st);
 // y = |A| |x| + |b|   (denominator of the componentwise backward error)
 void launch_csr_abs_spmv (const CsrDev &A, const double *x, const double *b, double *y, hipStream_t st);
 // host helper: greedy row-block partition (host arrays)

@@ -96,6 +96,12 @@ struct nkp_solver {
       int *send_idx = nullptr;        // local rows other ranks need, grouped by destination rank
       double *sendbuf = nullptr;      // packed values for them
       double *xe = nullptr;           // [n + n_halo] extended SpMV input: own rows then halo rows
+      // overlap of the halo exchange with the SpMV of the interior rows (rows without off-rank columns): the row blocks
+      // are built per segment [head boundary rows | interior | tail boundary rows]; seg_rb[q] = first row block of segment q
+      int seg_rb[4] = { 0, 0, 0, 0 };
+      bool overlap = false;
+      hipStream_t comm_stream = nullptr;
+      hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
    } dist;
    int64_t n = 0, ld = 0;
    int m = 0;
@@ -158,6 +164,9 @@ static void solver_free (nkp_solver *s)
    if (s->dist.send_idx) (void) hipFree (s->dist.send_idx);
    if (s->dist.sendbuf) (void) hipFree (s->dist.sendbuf);
    if (s->dist.xe) (void) hipFree (s->dist.xe);
+   if (s->dist.ev_packed) (void) hipEventDestroy (s->dist.ev_packed);
+   if (s->dist.ev_halo) (void) hipEventDestroy (s->dist.ev_halo);
+   if (s->dist.comm_stream) (void) hipStreamDestroy (s->dist.comm_stream);
    if (s->hpin) (void) hipHostFree (s->hpin);
    if (s->own_stream && s->stream) (void) hipStreamDestroy (s->stream);
    delete s;
@@ -205,10 +214,26 @@ static void spmv_op (nkp_solver *s, const double *x, double *y, const double *b,
    if (s->dist.on) {
       launch_copy (x, s->dist.xe, s->n, s->stream);
       if (s->dist.nsend) launch_gather (s->dist.send_idx, x, s->dist.sendbuf, s->dist.nsend, s->stream);
+      xin = s->dist.xe;
+      if (s->dist.overlap) {
+         // the exchange runs on its own stream behind the packing; the interior rows (no off-rank column) are multiplied
+         // meanwhile, the boundary rows once the halo has landed -- every row is still summed in stored order, so the
+         // result is the bit pattern of the serial version
+         (void) hipEventRecord (s->dist.ev_packed, s->stream);
+         (void) hipStreamWaitEvent (s->dist.comm_stream, s->dist.ev_packed, 0);
+         if (s->dist.ops.alltoallv (s->dist.ops.ctx, s->dist.sendbuf, s->dist.send_counts.data (), s->dist.xe + s->n,
+                                    s->dist.recv_counts.data (), (void *) s->dist.comm_stream))
+            s->comm_failed = true;
+         (void) hipEventRecord (s->dist.ev_halo, s->dist.comm_stream);
+         launch_csr_spmv_range (s->A, s->dist.seg_rb[1], s->dist.seg_rb[2], xin, y, b, mode, s->stream);
+         (void) hipStreamWaitEvent (s->stream, s->dist.ev_halo, 0);
+         launch_csr_spmv_range (s->A, s->dist.seg_rb[0], s->dist.seg_rb[1], xin, y, b, mode, s->stream);
+         launch_csr_spmv_range (s->A, s->dist.seg_rb[2], s->dist.seg_rb[3], xin, y, b, mode, s->stream);
+         return;
+      }
       if (s->dist.ops.alltoallv (s->dist.ops.ctx, s->dist.sendbuf, s->dist.send_counts.data (), s->dist.xe + s->n,
                                  s->dist.recv_counts.data (), (void *) s->stream))
          s->comm_failed = true;      // stale halo rows: checked before any verdict is returned
-      xin = s->dist.xe;
    }
    if (mode == 2) launch_csr_abs_spmv (s->A, xin, b, y, s->stream);
    else launch_csr_spmv (s->A, xin, y, b, mode, s->stream);
@@ -352,7 +377,34 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    }
    {
       int *rb = nullptr, nrb = 0;
-      build_rowblocks_host (n, M.rowptr, &rb, &nrb);
+      if (spmv_mat) {
+         // distributed flavour: row blocks per segment [head boundary | interior | tail boundary], where the interior is
+         // the longest run of rows without an off-rank (halo) column -- with latitude bands it is everything but the two
+         // or three latitude rows at either end of the band
+         int64_t lo = 0, hi = 0, run0 = 0;
+         for (int64_t r = 0; r <= n; r++) {
+            bool boundary = r == n;
+            for (int e = boundary ? 0 : M.rowptr[r]; !boundary && e < M.rowptr[r + 1]; e++) boundary = M.colind[e] >= n;
+            if (boundary) {
+               if (r - run0 > hi - lo) { lo = run0; hi = r; }
+               run0 = r + 1;
+            }
+         }
+         const int64_t seg[4] = { 0, lo, hi, n };
+         std::vector<int> all (1, 0);
+         for (int q = 0; q < 3; q++) {
+            s->dist.seg_rb[q] = (int) all.size () - 1;
+            int *part = nullptr, np = 0;
+            if (seg[q + 1] > seg[q]) build_rowblocks_host (seg[q + 1] - seg[q], M.rowptr + seg[q], &part, &np);
+            for (int i = 1; i <= np; i++) all.push_back ((int) seg[q] + part[i]);
+            free (part);
+         }
+         s->dist.seg_rb[3] = (int) all.size () - 1;
+         nrb = (int) all.size () - 1;
+         rb = (int *) malloc (all.size () * sizeof (int));
+         memcpy (rb, all.data (), all.size () * sizeof (int));
+      } else
+         build_rowblocks_host (n, M.rowptr, &rb, &nrb);
       s->A.nrowblk = nrb;
       rc = dev_alloc (s, &s->A.rowblk, (size_t) nrb + 1);
       if (rc == NKP_OK && hipMemcpy (s->A.rowblk, rb, ((size_t) nrb + 1) * sizeof (int), hipMemcpyHostToDevice) != hipSuccess)
@@ -533,6 +585,8 @@ extern "C" int64_t nkp_get_int (nkp_solver *s, const char *key)
    if (!strcmp (key, "device_bytes")) return (int64_t) s->device_bytes;
    if (!strcmp (key, "precond_steps")) return s->precond_steps;
    if (!strcmp (key, "equil")) return s->equil ? 1 : 0;
+   if (!strcmp (key, "dist_overlap")) return s->dist.overlap ? 1 : 0;
+   if (!strcmp (key, "dist_interior_rowblocks")) return s->dist.seg_rb[2] - s->dist.seg_rb[1];
    if (!strcmp (key, "smoother_spmv_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 0) : 0;
    if (!strcmp (key, "column_solve_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 1) : 0;
    if (!strcmp (key, "cycle_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 2) : 0;
@@ -1128,7 +1182,18 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
              dev_alloc (s, &s->dist.xe, (size_t) (m_loc + n_halo)) == NKP_OK;
    if (ok && nsend) ok = hipMemcpy (s->dist.send_idx, send_rows.data (), (size_t) nsend * sizeof (int), hipMemcpyHostToDevice) == hipSuccess;
    if (!ok) { solver_free (s); return fail (NKP_ENOMEM, "nkp_create_dist: halo buffers could not be allocated"); }
+   {
+      const char *e = getenv ("NKP_DIST_OVERLAP");
+      const bool want = !e || atoi (e) != 0;
+      const int interior_blocks = s->dist.seg_rb[2] - s->dist.seg_rb[1];
+      if (want && interior_blocks > 0 && hipStreamCreateWithFlags (&s->dist.comm_stream, hipStreamNonBlocking) == hipSuccess &&
+          hipEventCreateWithFlags (&s->dist.ev_packed, hipEventDisableTiming) == hipSuccess &&
+          hipEventCreateWithFlags (&s->dist.ev_halo, hipEventDisableTiming) == hipSuccess)
+         s->dist.overlap = true;
+   }
    s->dist.on = true;
+   msg (s, 1, "nkp_create_dist: %d of %d SpMV row blocks are interior (multiplied while the halo travels: %s)\n", s->dist.seg_rb[2] - s->dist.seg_rb[1],
+        s->dist.seg_rb[3], s->dist.overlap ? "yes" : "no");
    msg (s, 1, "nkp_create_dist: rows [%lld, %lld) of %lld, %lld halo rows in, %lld rows out\n", (long long) fst_row,
         (long long) (fst_row + m_loc), (long long) n_global, (long long) n_halo, (long long) nsend);
    *out = s;

@@ -421,6 +421,13 @@ void launch_csr_residual_range (const CsrDev &A, int rb0, int rb1, const double 
    launch_range<1> (A, rb0, rb1 - rb0, x, y, b, st);
 }
 
+void launch_csr_spmv_range (const CsrDev &A, int rb0, int rb1, const double *x, double *y, const double *b, int mode, hipStream_t st)
+{
+   if (mode == 0) launch_range<0> (A, rb0, rb1 - rb0, x, y, nullptr, st);
+   else if (mode == 1) launch_range<1> (A, rb0, rb1 - rb0, x, y, b, st);
+   else launch_range<2> (A, rb0, rb1 - rb0, x, y, b, st);
+}
+
 // ---------------------------------------------------------------- 2-byte column codes (host build)
 #include <algorithm>
 #include <vector>

@@ -74,6 +74,8 @@ def main():
         s = nd.NkpDistSolver(loc, n, comm, rtol=1e-10, restart=a.restart, max_iters=3000)
         # no set_stream: the solver keeps its own non-blocking stream and TorchComm orders every collective on the
         # stream the library passes to the callback (the wrapper must not depend on the caller)
+        result["dist_overlap"] = s.get_int("dist_overlap")
+        result["interior_rowblocks"] = s.get_int("dist_interior_rowblocks")
         y_loc = s.spmv(xg[f:f + m])
         y_ref = ora.spmv(p.rowptr, p.colind, p.nzval, xg)[f:f + m]
         result["spmv_bit_exact"] = bool(np.array_equal(y_loc, y_ref))

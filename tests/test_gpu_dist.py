@@ -15,6 +15,8 @@ def test_distributed_solve(tmp_path, world):
     assert all(r["status"] == 0 and r["relres"] <= 1e-10 for r in res), res
     assert res[0]["relres_checked"] <= 1.1e-10
     assert len({r["iters"] for r in res}) == 1                  # every rank took the same global decisions
+    # latitude bands: most rows have no off-rank column, their SpMV runs while the halo travels on a second stream
+    assert all(r["dist_overlap"] == 1 and r["interior_rowblocks"] > 0 for r in res), res
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -27,6 +29,8 @@ def test_distributed_solve_one_tracer_per_rank(tmp_path, world):
     assert all(r["status"] == 0 and r["relres"] <= 1e-10 for r in res), res
     assert res[0]["relres_checked"] <= 1.1e-10
     assert len({r["iters"] for r in res}) == 1
+    # every row couples to the other tracers' copy of its cell: no interior rows, nothing to overlap
+    assert all(r["dist_overlap"] == 0 for r in res), res
 
 
 def test_solve_ABdist_cli_with_builtin_rccl(tmp_path, golden_by_name):
