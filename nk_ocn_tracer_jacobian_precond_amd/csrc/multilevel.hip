@@ -1028,6 +1028,13 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
             V.wave_columns = ncol <= wave_max && V.B.dropped == 0;
             t_lay += secs (t_lay0);
          }
+         // f32 storage mode: the f64 copy of the level operator was only needed to factor the column blocks
+         if (V.L.valf && V.L.val) {
+            (void) hipStreamSynchronize (st);
+            (void) hipFree (V.L.val);
+            V.L.val = nullptr;
+            H.device_bytes -= ((size_t) prow[nl] + 2) * sizeof (double);
+         }
       }
       if (l < nlev - 1) {
          // transfer operators in permuted orders

@@ -70,3 +70,15 @@ def test_coarsest_level_without_dense_inverse(monkeypatch):
     info = _solve(p)
     assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
     assert info["iters"] <= 2 * ref["iters"] + 10, (info, ref)
+
+
+@pytest.mark.parametrize("adv,hmix,max_iters", [("donor", "isop", 120), ("centred", "isop", 600), ("upwind3", "const", 400), ("centred", "const", 900),
+                                                ("none", "const", 120)])
+def test_operator_families_at_3_degrees(adv, hmix, max_iters):
+    """Every advection / lateral-mixing family the reference's gen_A offers (src/gen_A.c:170-216), on the 3 degree x 60 grid
+    of BASELINE configs[1]: the solve must meet 1e-10 on the oracle-recomputed residual within a bound that documents how
+    hard the family is for the low-order twin (centred advection, the reference's default, is the hardest)."""
+    p = synth.generate(imt=100, jmt=116, km=60, adv=adv, hmix=hmix, seed=0)
+    info = _solve(p, max_iters=3000)
+    assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
+    assert info["iters"] <= max_iters, info
