@@ -799,7 +799,7 @@ void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, cons
       N.nagg = n2;
       Nat C;
       int64_t ncr = 0;
-      static int split = -1, pocket = 16;
+      static int split = -1, pocket = 4;
       static double theta = 0.0, tau = 0.01;
       if (split < 0) {
          const char *e = getenv ("NKP_ML_SPLIT");

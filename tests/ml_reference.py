@@ -36,7 +36,7 @@ class Level:
     pass
 
 
-def split_groups(L, I, J, ck, colid, pocket=16, theta=0.0, tau=0.01):
+def split_groups(L, I, J, ck, colid, pocket=4, theta=0.0, tau=0.01):
     """Coarse cells of one coarsening step.  I, J: group coordinates of every row; ck: depth of every row; colid: column
     of every row (rows of a column are contiguous and ordered by depth).  Returns (coarse row of every fine row, and per
     coarse row: I, J, depth, coarse column)."""
