@@ -762,9 +762,15 @@ void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, cons
          // 2 x 2 on the big levels, 4 x 4 from level 3 down: every kernel of a small level runs at its latency
          // floor, so fewer small levels pay (1 degree: 8 -> 6 levels, +5 % iterations, -14 % cycle time);
          // NKP_ML_BIG_FROM=l moves the switch, -1 disables it (from level 2 it costs +68 % iterations)
+         // (round 2, with the connectivity-aware cells and omega = 1.1: grids of fewer than 200 000 columns per tracer
+         // keep the switch at level 3 -- 1 degree: 64 iterations / 0.21 s either way -- larger grids coarsen 2 x 2 all the
+         // way, where the better hierarchy outweighs two more latency-bound levels: 0.5 degree 92 -> 79 iterations,
+         // 0.95 -> 0.81 s; 0.25 degree 129 -> 105, 4.1 -> 3.4 s)
          static int big_from = -2;
-         if (big_from == -2) { const char *e = getenv ("NKP_ML_BIG_FROM"); big_from = e ? atoi (e) : 3; }
-         const int sh = (big_from >= 0 && l >= big_from) ? 2 : 1;
+         if (big_from == -2) { const char *e = getenv ("NKP_ML_BIG_FROM"); big_from = e ? atoi (e) : -3; }
+         int bf = big_from;
+         if (bf == -3) bf = ((int) nat[0].blk_start.size () - 1) / (tracer_cnt > 0 ? tracer_cnt : 1) >= 200000 ? -1 : 3;
+         const int sh = (bf >= 0 && l >= bf) ? 2 : 1;
          for (int c = 0; c < ncol; c++) keys[c] = { { N.gt[c], N.gj[c] >> sh, N.gi[c] >> sh }, c };
          std::vector<std::pair<std::array<int, 3>, int>> sorted (keys);
          std::sort (sorted.begin (), sorted.end ());
@@ -1149,7 +1155,9 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
 {
    if (H.omega == 0.0) {
       const char *e = getenv ("NKP_ML_OMEGA");
-      H.omega = (e && atof (e) > 0.0) ? atof (e) : 1.0;
+      // 1.1: the Galerkin operators of piecewise-constant cells are too stiff where lateral mixing matters, so a slightly
+      // over-weighted coarse correction helps (1 degree: 0.9 -> 77 iterations, 1.0 -> 69, 1.1 -> 64, 1.2 -> 68, 1.35 -> 95)
+      H.omega = (e && atof (e) > 0.0) ? atof (e) : 1.1;
       if ((e = getenv ("NKP_ML_GAMMA_FROM"))) H.gamma_from = atoi (e);
       if ((e = getenv ("NKP_ML_GAMMA_TO"))) H.gamma_to = atoi (e);
    }
