@@ -31,6 +31,7 @@ ap.add_argument("--min-cos", type=float, default=0.3)
 ap.add_argument("--refine", type=float, default=1.0, help="cell-level coefficients of a grid this many times finer (u x F, ah x F^2)")
 ap.add_argument("--k33", type=int, default=1, help="isop: include the K33 vertical term of the Redi tensor")
 ap.add_argument("--precond-steps", type=int, default=0)
+ap.add_argument("--basis-f32", type=int, default=0)
 a = ap.parse_args()
 imt, jmt, km = (int(t) for t in a.grid.split("x"))
 t0 = time.time()
@@ -41,7 +42,7 @@ ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), a.tracers)
 tgen = time.time() - t0
 t0 = time.time()
 s = solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=None if a.no_geo else ci, col_j=None if a.no_geo else cj, coupled_tracer_cnt=a.tracers, restart=a.restart, max_iters=a.max_iters, rtol=a.rtol,
-                     precond=a.precond, krylov=a.krylov, reorth=a.reorth, verbose=a.verbose, ml_smooth=a.ml_smooth, ml_levels=a.ml_levels, precond_steps=a.precond_steps)
+                     precond=a.precond, krylov=a.krylov, reorth=a.reorth, verbose=a.verbose, ml_smooth=a.ml_smooth, ml_levels=a.ml_levels, precond_steps=a.precond_steps, basis_f32=a.basis_f32)
 tsetup = time.time() - t0
 res = dict(grid=a.grid, refine=a.refine, k33=a.k33, adv=a.adv, hmix=a.hmix, precond=a.precond, levels=s.get_int("levels"), ml_rows=s.get_int("ml_rows"), ml_nnz=s.get_int("ml_nnz"), n=p.flat_len, nnz=p.nnz, gen_s=round(tgen, 2), setup_s=round(tsetup, 3))
 ms = s.time_kernel(0, reps=50)
