@@ -245,7 +245,23 @@ def main():
                 starts = nd.snap_partition(blk, world)
                 loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, rank, ci, cj)
                 mode = f"strong scaling: rows split into {world} latitude bands, halo alltoallv + allreduce over RCCL (torch.distributed), rank-local multilevel preconditioner"
-            comm = nd.RcclComm() if (a.comm == "rccl" and backend == "nccl") else nd.TorchComm()
+            comm = None
+            if a.comm == "rccl" and backend == "nccl":
+                # the library's own communicator, checked before anything is built on it: a wrong answer or a call that
+                # never returns sends EVERY rank to the torch.distributed callbacks (same decision on all ranks)
+                good = 1
+                try:
+                    comm = nd.RcclComm()
+                    nd.comm_self_test(comm, timeout=120.0)
+                except Exception as exc:
+                    print(f"({rank}) library RCCL communicator failed its self-test, using torch.distributed callbacks: {exc!r}", file=sys.stderr)
+                    good = 0
+                flag = torch.tensor([good], device="cuda")
+                all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    comm = None
+            if comm is None:
+                comm = nd.TorchComm()
             mode += f"; collectives: {'library RCCL communicator (comm_rccl.hip)' if isinstance(comm, nd.RcclComm) else 'torch.distributed callbacks'}"
             s = nd.NkpDistSolver(loc, n_global, comm, coupled_tracer_cnt=cnt_loc, **kw)
             fst = loc["fst_row"]
@@ -356,7 +372,7 @@ def main():
     kernels = []
     if not distributed:
         for label, which, key, reps in (("csr_spmv_pipe_kernel<1, float> (smoother residual rows, fine level, one colour)", 3, "smoother_spmv_bytes", 100),
-                                        ("colblock_apply_lanes_kernel (water-column solves, fine level, one colour)", 4, "column_solve_bytes", 100),
+                                        ("colblock_apply_stream_kernel (water-column solves, fine level, one colour; the lanes kernel below 50 000 columns)", 4, "column_solve_bytes", 100),
                                         ("whole V-cycle (all levels, ~150 launches)", 1, "cycle_bytes", 50)):
             ms = pre_ms if which == 1 else s.time_kernel(which, reps=reps)
             nbytes = s.get_int(key)

@@ -228,10 +228,11 @@ class RcclComm:
         self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
         self.errors = []
         ident = (C.c_ubyte * 128)()
-        if self.rank == 0 and lib.nkp_comm_unique_id(ident) != 0:
-            raise _solver.NkpError(-5, "nkp_comm_unique_id failed")
-        box = [bytes(ident)]
+        made = self.rank != 0 or lib.nkp_comm_unique_id(ident) == 0
+        box = [bytes(ident) if made else None]        # rank 0's failure reaches every rank instead of leaving them waiting
         dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise _solver.NkpError(-5, "nkp_comm_unique_id failed on rank 0")
         ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
         self.ops = _solver.NkpCommOps()
         lib.nkp_comm_rccl_init.argtypes = [C.POINTER(_solver.NkpCommOps), C.c_void_p, C.c_int, C.c_int]
@@ -243,6 +244,64 @@ class RcclComm:
         if self.ops.ctx:
             self._lib.nkp_comm_rccl_free.argtypes = [C.POINTER(_solver.NkpCommOps)]
             self._lib.nkp_comm_rccl_free(C.byref(self.ops))
+
+
+def comm_self_test(comm, timeout=120.0):
+    """Pre-flight of a transport before a solver is built on it: one sum and one max allreduce and one personalised
+    exchange with rank-dependent counts, checked against the values every rank must end with.  The calls run in a
+    helper thread so that a transport that never returns is reported (TimeoutError) instead of hanging the job.
+    Collective: every rank calls it."""
+    import threading
+    import torch
+    ops, rank, nranks = comm.ops, comm.ops.rank, comm.ops.nranks
+    device = torch.cuda.current_device()
+    out = {}
+
+    def cnt(a, b):                                  # symmetric, so what a sends b is what b expects from a
+        return (a + b) % 3 + 1
+
+    def run():
+        try:
+            torch.cuda.set_device(device)
+            st = torch.cuda.Stream()
+            sp = C.c_void_p(st.cuda_stream)
+            buf = torch.full((4,), float(rank + 1), dtype=torch.float64, device="cuda")
+            st.wait_stream(torch.cuda.current_stream())
+            if ops.allreduce(ops.ctx, C.c_void_p(buf.data_ptr()), 4, 0, sp):
+                raise RuntimeError("allreduce(sum) returned an error")
+            st.synchronize()
+            want = nranks * (nranks + 1) / 2.0
+            if not bool((buf == want).all()):
+                raise RuntimeError(f"allreduce(sum) gave {buf.tolist()}, expected {want}")
+            buf.fill_(float(rank))
+            torch.cuda.current_stream().synchronize()
+            if ops.allreduce(ops.ctx, C.c_void_p(buf.data_ptr()), 4, 1, sp):
+                raise RuntimeError("allreduce(max) returned an error")
+            st.synchronize()
+            if not bool((buf == float(nranks - 1)).all()):
+                raise RuntimeError(f"allreduce(max) gave {buf.tolist()}")
+            sc = (C.c_int * nranks)(*[cnt(rank, p) for p in range(nranks)])
+            send = torch.cat([torch.full((cnt(rank, p),), 100.0 * rank + p, dtype=torch.float64) for p in range(nranks)]).cuda()
+            recv = torch.full((int(send.numel()),), -1.0, dtype=torch.float64, device="cuda")
+            torch.cuda.current_stream().synchronize()
+            if ops.alltoallv(ops.ctx, C.c_void_p(send.data_ptr()), sc, C.c_void_p(recv.data_ptr()), sc, sp):
+                raise RuntimeError("alltoallv returned an error")
+            st.synchronize()
+            expect = torch.cat([torch.full((cnt(rank, p),), 100.0 * p + rank, dtype=torch.float64) for p in range(nranks)])
+            if not bool((recv.cpu() == expect).all()):
+                raise RuntimeError("alltoallv delivered the wrong values")
+            out["ok"] = True
+        except Exception as exc:
+            out["error"] = exc
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        raise TimeoutError(f"transport self-test did not return within {timeout:.0f} s")
+    if "error" in out:
+        raise out["error"]
+    return True
 
 
 class NkpDistSolver(_solver.NkpSolver):

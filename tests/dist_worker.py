@@ -71,6 +71,7 @@ def main():
     else:
         torch.cuda.set_device(0)
         b = rng.standard_normal(n)
+        result["self_test"] = bool(nd.comm_self_test(comm, timeout=60.0))   # the pre-flight bench.py runs on its transport
         s = nd.NkpDistSolver(loc, n, comm, rtol=1e-10, restart=a.restart, max_iters=3000)
         # no set_stream: the solver keeps its own non-blocking stream and TorchComm orders every collective on the
         # stream the library passes to the callback (the wrapper must not depend on the caller)

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 def test_distributed_solve(tmp_path, world):
     res = launch(world, "gpu-solve", str(tmp_path / "solve"), extra=("--grid", "40x46x20"))
     assert all(r["spmv_bit_exact"] for r in res), res
+    assert all(r["self_test"] for r in res), res                # the transport pre-flight bench.py runs (comm_self_test)
     assert all(not r["comm_errors"] for r in res), res
     assert all(r["status"] == 0 and r["relres"] <= 1e-10 for r in res), res
     assert res[0]["relres_checked"] <= 1.1e-10
@@ -114,3 +115,25 @@ def test_stale_rccl_id_file_is_ignored(tmp_path, golden_by_name):
     r = subprocess.run([exe, "-v", "IAGE", g.matrix_path, dst], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr + r.stdout
     assert not idfile.exists()                                  # rank 0 removed its id once the communicator existed
+
+
+def test_bench_distributed_path_on_one_rank(tmp_path):
+    """bench.py's N > 1 code path (configs[3] layout, library RCCL communicator after its pre-flight self-test, barriers,
+    max-over-ranks timing) driven with a single rank: RCCL wants one GPU per rank and the test box has one."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--grid", "40x46x20", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--rhs-batch", "0", "--round1-steps", "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "library RCCL communicator" in line["config"]["multi_gpu"], line["config"]
+    assert "FALLBACK" not in line["config"]["multi_gpu"]
+    assert "self-test" not in out.stderr, out.stderr[-2000:]
+    assert line["value"] > 0 and max(line["solve"]["relres"]) <= 1e-10
+    assert line["solve"]["relres_checked_with_torch"] <= 1.1e-10
