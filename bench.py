@@ -214,7 +214,7 @@ def main():
     s = None
     if world > 1 or a.force_dist:
         # The reference's contiguous row-block partition (src/solve_ABdist.c:141-144), halo exchange + allreduce
-        # through torch.distributed's RCCL communicator, rank-local multilevel preconditioner.
+        # through torch.distributed's RCCL communicator, multilevel hierarchy per rank with one ring of the neighbours' water columns where the cut is lateral (restricted additive Schwarz).
         try:
             if a.multi_gpu == "c4":
                 # BASELINE configs[3]: 4 coupled tracers, tracer-major rows (src/matrix.c:778-784); the n/P rule gives a rank
@@ -232,19 +232,19 @@ def main():
                 del p4
                 mode = (f"configs[3]: 4-tracer coupled system ({n_global} rows) split into {world} contiguous row blocks "
                         f"({'%d tracer(s)' % (4 // world) if world <= 4 else 'a latitude band of one tracer'} per GPU), halo alltoallv + "
-                        f"allreduce over RCCL (torch.distributed), rank-local multilevel preconditioner")
+                        f"allreduce over RCCL (torch.distributed), multilevel hierarchy per rank with one ring of the neighbours' water columns where the cut is lateral (restricted additive Schwarz)")
             elif a.multi_gpu == "weak":
                 tracers_global = world
                 cnt_loc = 1
                 loc, starts, n_global = nd.tracer_slice(p, rank, world)
                 nnz_global = world * (p.nnz + (world - 1) * p.flat_len)
                 mode = (f"weak scaling: {world}-tracer coupled system, one tracer ({p.flat_len} rows) per GPU, halo alltoallv "
-                        f"({world - 1} x {p.flat_len} values per SpMV) + allreduce over RCCL (torch.distributed), rank-local multilevel preconditioner")
+                        f"({world - 1} x {p.flat_len} values per SpMV) + allreduce over RCCL (torch.distributed), multilevel hierarchy per rank with one ring of the neighbours' water columns where the cut is lateral (restricted additive Schwarz)")
             else:
                 cnt_loc = 1
                 starts = nd.snap_partition(blk, world)
                 loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, rank, ci, cj)
-                mode = f"strong scaling: rows split into {world} latitude bands, halo alltoallv + allreduce over RCCL (torch.distributed), rank-local multilevel preconditioner"
+                mode = f"strong scaling: rows split into {world} latitude bands, halo alltoallv + allreduce over RCCL (torch.distributed), multilevel hierarchy per rank with one ring of the neighbours' water columns where the cut is lateral (restricted additive Schwarz)"
             comm = None
             if a.comm == "rccl" and backend == "nccl":
                 # the library's own communicator, checked before anything is built on it: a wrong answer or a call that

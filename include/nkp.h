@@ -155,7 +155,9 @@ int nkp_multi_dot (nkp_solver *s, const double *V, int64_t ld, int k, const doub
 int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, double *avg_ms);
 
 /* Introspection: key = "n", "nnz", "nblk", "band", "levels", "spmv_bytes", "device_bytes", "precond_steps", "equil";
- * compulsory HBM bytes of the pieces nkp_time_kernel times: "smoother_spmv_bytes", "column_solve_bytes", "cycle_bytes". */
+ * compulsory HBM bytes of the pieces nkp_time_kernel times: "smoother_spmv_bytes", "column_solve_bytes", "cycle_bytes";
+ * distributed flavour: "dist_overlap" (halo exchange hidden behind the interior rows), "dist_interior_rowblocks",
+ * "dist_ras" (hierarchy overlaps the neighbouring ranks), "dist_ras_rows" (rows of other ranks in this rank's hierarchy). */
 int64_t nkp_get_int (nkp_solver *s, const char *key);
 
 /* Use an externally owned HIP stream (hipStream_t cast to void*) instead of the solver's own;
@@ -204,8 +206,10 @@ void nkp_comm_file_free (nkp_comm_ops *ops);
  * blk_start_loc holds the local block offsets (relative to fst_row, blk_start_loc[nblk_loc] =
  * m_loc); a water column must not straddle ranks.  Collective over all ranks.
  * The Krylov iteration is global (halo exchange before every SpMV, one allreduce per
- * Gram-Schmidt pass); the multilevel preconditioner is built from the rank's own diagonal block
- * (non-overlapping Schwarz).  nkp_solve / nkp_solve_device then take and return the LOCAL slice
+ * Gram-Schmidt pass); the multilevel preconditioner is one hierarchy per rank that, where the cut is
+ * lateral (opt->col_i / col_j given), also covers one ring of the neighbouring ranks' water columns
+ * (restricted additive Schwarz: setup fetches those rows from their owners through alltoallv_i32_host,
+ * every application fetches their residual through alltoallv; NKP_DIST_RAS=0 = diagonal block only).  nkp_solve / nkp_solve_device then take and return the LOCAL slice
  * of b / x, like pdgssvx with ldb = m_loc (src/solve_ABdist.c:571). */
 int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global, int64_t fst_row,
                      int64_t m_loc, int64_t nnz_loc, const int32_t *rowptr_loc,

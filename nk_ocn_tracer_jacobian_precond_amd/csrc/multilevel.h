@@ -42,7 +42,8 @@ struct MlHierarchy {
 
 // returns 0, or a negative nkp error code with a message in err
 int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, const double *val,
-              const int *blk_start, int64_t nblk, const int *col_i, const int *col_j, int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
+              const int *blk_start, int64_t nblk, const int *col_i, const int *col_j, const int *col_t /* tracer of every column, or NULL = positional */,
+              int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
               hipStream_t st, char *err, size_t errlen);
 void ml_free (MlHierarchy &H);
 // z = V-cycle(r) in the ORIGINAL row order

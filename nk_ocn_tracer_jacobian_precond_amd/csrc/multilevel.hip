@@ -705,7 +705,7 @@ struct SetupTimes { double low = 0.0, graph = 0.0, galerkin = 0.0; };
 
 // twin, colouring, aggregation and Galerkin product of every level; host only (no HIP call)
 void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, const int *colind, const double *val, const int *blk_start_in, int64_t nblk,
-                       const int *col_i, const int *col_j, int tracer_cnt, int max_levels, int coarsest_rows, int verbose, int rank, SetupTimes &T)
+                       const int *col_i, const int *col_j, const int *col_t, int tracer_cnt, int max_levels, int coarsest_rows, int verbose, int rank, SetupTimes &T)
 {
    using clk = std::chrono::steady_clock;
    auto secs = [] (clk::time_point a) { return std::chrono::duration<double> (clk::now () - a).count (); };
@@ -724,7 +724,9 @@ void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, cons
          N.gj.assign (col_j, col_j + nblk);
          N.gt.resize (nblk);
          const int64_t per = (tracer_cnt > 1 && nblk % tracer_cnt == 0) ? nblk / tracer_cnt : nblk;
-         for (int64_t c = 0; c < nblk; c++) N.gt[c] = (int) (c / per);
+         // tracer of a column: positional (tracer-major rows, src/matrix.c:778-784) unless the caller names it -- the
+         // distributed flavour appends the neighbouring ranks' overlap columns behind its own
+         for (int64_t c = 0; c < nblk; c++) N.gt[c] = col_t ? col_t[c] : (int) (c / per);
       }
    }
    for (int l = 0;; l++) {
@@ -864,7 +866,7 @@ extern "C" int nkp_ml_plan_host (int64_t n, const int32_t *rowptr, const int32_t
    if (max_levels <= 0) max_levels = 12;
    std::vector<Nat> nat;
    SetupTimes T;
-   build_nat_levels (nat, n, rowptr, colind, val, blk_start, nblk, col_i, col_j, coupled_tracer_cnt, max_levels, coarsest_rows, 0, 0, T);
+   build_nat_levels (nat, n, rowptr, colind, val, blk_start, nblk, col_i, col_j, nullptr, coupled_tracer_cnt, max_levels, coarsest_rows, 0, 0, T);
    if (getenv ("NKP_ML_PLAN_TIMES")) printf ("nkp_ml_plan_host: %.2f s low-order twin, %.2f s graphs + aggregation, %.2f s Galerkin products\n", T.low, T.graph, T.galerkin);
    *n_levels = (int) nat.size ();
    int64_t qc = 0, qo = 0;
@@ -883,7 +885,7 @@ extern "C" int nkp_ml_plan_host (int64_t n, const int32_t *rowptr, const int32_t
 
 // ================================================================ setup
 int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, const double *val,
-              const int *blk_start_in, int64_t nblk, const int *col_i, const int *col_j, int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
+              const int *blk_start_in, int64_t nblk, const int *col_i, const int *col_j, const int *col_t, int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
               hipStream_t st, char *err, size_t errlen)
 {
 #define ML_FAIL(code, ...) do { snprintf (err, errlen, __VA_ARGS__); return (code); } while (0)
@@ -908,7 +910,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
    std::vector<Nat> nat;
    {
       SetupTimes T;
-      build_nat_levels (nat, n, rowptr, colind, val, blk_start_in, nblk, col_i, col_j, tracer_cnt, max_levels, coarsest_rows, verbose, rank, T);
+      build_nat_levels (nat, n, rowptr, colind, val, blk_start_in, nblk, col_i, col_j, col_t, tracer_cnt, max_levels, coarsest_rows, verbose, rank, T);
       t_low = T.low; t_graph = T.graph; t_galerkin = T.galerkin;
    }
 

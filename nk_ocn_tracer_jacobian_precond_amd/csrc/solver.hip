@@ -102,6 +102,12 @@ struct nkp_solver {
       bool overlap = false;
       hipStream_t comm_stream = nullptr;
       hipEvent_t ev_packed = nullptr, ev_halo = nullptr;
+      // restricted additive Schwarz: the hierarchy of this rank also covers the neighbouring ranks' water columns its rows
+      // couple to laterally (one ring); a cycle runs on [own rows | those halo rows] and only the own part is kept
+      bool ras = false;
+      int64_t n_ext = 0, n_sel = 0;
+      int *sel_idx = nullptr;         // position in the halo of every overlap row
+      double *rext = nullptr, *zext = nullptr;
    } dist;
    int64_t n = 0, ld = 0;
    int m = 0;
@@ -164,6 +170,9 @@ static void solver_free (nkp_solver *s)
    if (s->dist.send_idx) (void) hipFree (s->dist.send_idx);
    if (s->dist.sendbuf) (void) hipFree (s->dist.sendbuf);
    if (s->dist.xe) (void) hipFree (s->dist.xe);
+   if (s->dist.sel_idx) (void) hipFree (s->dist.sel_idx);
+   if (s->dist.rext) (void) hipFree (s->dist.rext);
+   if (s->dist.zext) (void) hipFree (s->dist.zext);
    if (s->dist.ev_packed) (void) hipEventDestroy (s->dist.ev_packed);
    if (s->dist.ev_halo) (void) hipEventDestroy (s->dist.ev_halo);
    if (s->dist.comm_stream) (void) hipStreamDestroy (s->dist.comm_stream);
@@ -188,7 +197,17 @@ static void msg (const nkp_solver *s, int lvl, const char *fmt, ...)
 static void apply_precond_once (nkp_solver *s, const double *rin, double *zout)
 {
    if (s->opt.precond == NKP_PRECOND_NONE) launch_copy (rin, zout, s->n, s->stream);
-   else if (s->opt.precond == NKP_PRECOND_MULTILEVEL) ml_apply (s->ml, rin, zout, s->stream);
+   else if (s->opt.precond == NKP_PRECOND_MULTILEVEL && s->dist.ras) {
+      // the residual on the overlap rows comes from their owners (same exchange pattern as the SpMV's halo)
+      if (s->dist.nsend) launch_gather (s->dist.send_idx, rin, s->dist.sendbuf, s->dist.nsend, s->stream);
+      if (s->dist.ops.alltoallv (s->dist.ops.ctx, s->dist.sendbuf, s->dist.send_counts.data (), s->dist.xe + s->n,
+                                 s->dist.recv_counts.data (), (void *) s->stream))
+         s->comm_failed = true;
+      launch_copy (rin, s->dist.rext, s->n, s->stream);
+      if (s->dist.n_sel) launch_gather (s->dist.sel_idx, s->dist.xe + s->n, s->dist.rext + s->n, s->dist.n_sel, s->stream);
+      ml_apply (s->ml, s->dist.rext, s->dist.zext, s->stream);
+      launch_copy (s->dist.zext, zout, s->n, s->stream);
+   } else if (s->opt.precond == NKP_PRECOND_MULTILEVEL) ml_apply (s->ml, rin, zout, s->stream);
    else launch_colblock_apply_lanes (s->B, 0, s->B.ngrp, rin, zout, 0, s->stream);
 }
 
@@ -251,10 +270,19 @@ struct SpmvMatrixHost {
    const int32_t *rowptr, *colind;
    const double *val;
 };
+// the matrix the multilevel hierarchy is built from when it is not the solver's own n x n block (distributed flavour
+// with overlap: own rows followed by the overlap rows, columns renumbered accordingly)
+struct PrecondMatrixHost {
+   int64_t n, nblk;
+   const int32_t *rowptr, *colind;
+   const double *val;
+   const int32_t *blk_start, *col_i, *col_j, *col_t;
+};
 
 static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, int64_t nnz,
                         const int32_t *rowptr, const int32_t *colind, const double *val,
-                        const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt, const SpmvMatrixHost *spmv_mat)
+                        const int32_t *blk_start, int64_t nblk, int coupled_tracer_cnt, const SpmvMatrixHost *spmv_mat,
+                        const PrecondMatrixHost *pm = nullptr)
 {
    if (!out) return fail (NKP_EINVAL, "nkp_create: out is NULL");
    *out = nullptr;
@@ -472,8 +500,11 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
          colind = f_colind.data ();
          val = f_val.data ();
       }
-      const int mrc = ml_setup (s->ml, n, rowptr, colind, val, blk_start, nblk, blk_default.empty () ? opt.col_i : nullptr, blk_default.empty () ? opt.col_j : nullptr, coupled_tracer_cnt, opt.ml_levels, opt.ml_smooth,
-                                 getenv ("NKP_ML_COARSEST_ROWS") ? atoi (getenv ("NKP_ML_COARSEST_ROWS")) : 3000 /* dense inverse on the device: one tiny level less at 3 degrees, cycle 1.15 -> 0.96 ms */, opt.verbose, opt.rank, s->stream, err, sizeof err);
+      const int coarsest_rows = getenv ("NKP_ML_COARSEST_ROWS") ? atoi (getenv ("NKP_ML_COARSEST_ROWS")) : 3000;   // dense inverse on the device: one tiny level less at 3 degrees, cycle 1.15 -> 0.96 ms
+      const int mrc = pm ? ml_setup (s->ml, pm->n, pm->rowptr, pm->colind, pm->val, pm->blk_start, pm->nblk, pm->col_i, pm->col_j, pm->col_t, coupled_tracer_cnt, opt.ml_levels,
+                                     opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err)
+                         : ml_setup (s->ml, n, rowptr, colind, val, blk_start, nblk, blk_default.empty () ? opt.col_i : nullptr, blk_default.empty () ? opt.col_j : nullptr, nullptr,
+                                     coupled_tracer_cnt, opt.ml_levels, opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err);
       if (mrc != 0) {
          rc = fail (mrc, "nkp_create: %s", err);
          solver_free (s);
@@ -587,6 +618,8 @@ extern "C" int64_t nkp_get_int (nkp_solver *s, const char *key)
    if (!strcmp (key, "precond_steps")) return s->precond_steps;
    if (!strcmp (key, "equil")) return s->equil ? 1 : 0;
    if (!strcmp (key, "dist_overlap")) return s->dist.overlap ? 1 : 0;
+   if (!strcmp (key, "dist_ras")) return s->dist.ras ? 1 : 0;
+   if (!strcmp (key, "dist_ras_rows")) return s->dist.n_sel;
    if (!strcmp (key, "dist_interior_rowblocks")) return s->dist.seg_rb[2] - s->dist.seg_rb[1];
    if (!strcmp (key, "smoother_spmv_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 0) : 0;
    if (!strcmp (key, "column_solve_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 1) : 0;
@@ -1144,7 +1177,242 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
       send_rows[q] -= (int32_t) fst_row;
       if (send_rows[q] < 0 || send_rows[q] >= m_loc) return fail (NKP_ECOMM, "nkp_create_dist: a peer asked for a row this rank does not own");
    }
-   // diagonal block for the rank-local preconditioner
+   nkp_options o;
+   if (opt) o = *opt;
+   else nkp_default_options (&o);
+   o.rank = rank;
+
+   // ---- restricted additive Schwarz (overlap of one ring of water columns) -------------------------------------------
+   // A hierarchy built from the rank's diagonal block alone treats the cut through the ocean as a wall: latitude bands cost
+   // 2-3 times the iterations of the undivided solve (1 degree: 78 / 157 / 238 for 1 / 2 / 4 bands), and a global coarsest
+   // level does not repair that (scipy prototype tools/proto_bands.py: 36 / 58 / 89 without, 57 / 87 with it).  What does is
+   // the classical remedy: every rank's hierarchy also covers the water columns of other ranks that its own rows couple to
+   // LATERALLY (the halo of the SpMV, completed to whole columns), a cycle runs on [own rows | overlap rows] with the
+   // residual of the overlap rows fetched from their owners, and only the own part of the result is kept (prototype:
+   // 36 / 43 / 55).  Columns of OTHER TRACERS at a cell this rank owns are not overlap (a tracer-per-rank partition keeps
+   // its block-Jacobi preconditioner): a halo column joins only if its (i, j) is not the position of an own column.
+   const bool geo = o.col_i && o.col_j && blk_start_loc && nblk_loc > 0;
+   int64_t want_ras = (o.precond == NKP_PRECOND_MULTILEVEL && geo) ? 1 : 0;
+   { const char *e = getenv ("NKP_DIST_RAS"); if (e && atoi (e) == 0) want_ras = 0; }
+   {
+      std::vector<int64_t> all (P + 1, 0);
+      if (comm->allgather_i64_host (comm->ctx, want_ras, all.data ())) return fail (NKP_ECOMM, "nkp_create_dist: allgather failed");
+      for (int p = 0; p < P; p++) want_ras = want_ras && all[p];
+   }
+   std::vector<int32_t> e_rowptr, e_colind, e_blk, e_ci, e_cj, e_ct, sel_hpos;
+   std::vector<double> e_val;
+   int64_t n_sel = 0;
+   bool ras = false;
+   if (want_ras) {
+#define XCHG(sendp, scnt, recvp, rcnt, what) do { if (comm->alltoallv_i32_host (comm->ctx, (sendp), (scnt), (recvp), (rcnt))) return fail (NKP_ECOMM, "nkp_create_dist: %s exchange failed", what); } while (0)
+      std::vector<int32_t> col_of ((size_t) m_loc + 1);
+      for (int64_t c = 0; c < nblk_loc; c++)
+         for (int r = blk_start_loc[c]; r < blk_start_loc[c + 1]; r++) col_of[(size_t) r] = (int32_t) c;
+      // owner: complete every requested row to its water column
+      std::vector<int> give_rows (P, 0), give_cols (P, 0), need_rows (P, 0), need_cols (P, 0), twos (P, 2), pair_s (2 * (size_t) P), pair_r (2 * (size_t) P);
+      std::vector<int32_t> out_rows, out_cols;
+      {
+         size_t q = 0;
+         for (int p = 0; p < P; p++) {
+            int last = -1;
+            for (int k = 0; k < give[p]; k++, q++) {
+               const int c = col_of[(size_t) send_rows[q]];
+               if (c == last) continue;
+               last = c;
+               out_cols.push_back (c);
+               give_cols[p]++;
+               for (int r = blk_start_loc[c]; r < blk_start_loc[c + 1]; r++) { out_rows.push_back (r); give_rows[p]++; }
+            }
+            pair_s[2 * (size_t) p] = give_rows[p];
+            pair_s[2 * (size_t) p + 1] = give_cols[p];
+         }
+      }
+      XCHG (pair_s.data (), twos.data (), pair_r.data (), twos.data (), "overlap count");
+      int64_t n_halo2 = 0, n_hcol = 0;
+      for (int p = 0; p < P; p++) { need_rows[p] = pair_r[2 * (size_t) p]; need_cols[p] = pair_r[2 * (size_t) p + 1]; n_halo2 += need_rows[p]; n_hcol += need_cols[p]; }
+      // the completed halo: global row ids, then (length, i, j) of every halo column
+      std::vector<int32_t> ids_s (out_rows.size () + 1), halo2 ((size_t) n_halo2 + 1);
+      for (size_t k = 0; k < out_rows.size (); k++) ids_s[k] = out_rows[k] + (int32_t) fst_row;
+      XCHG (ids_s.data (), give_rows.data (), halo2.data (), need_rows.data (), "overlap row");
+      std::vector<int> give3 (P), need3 (P);
+      for (int p = 0; p < P; p++) { give3[p] = 3 * give_cols[p]; need3[p] = 3 * need_cols[p]; }
+      std::vector<int32_t> meta_s (3 * out_cols.size () + 1), meta_r (3 * (size_t) n_hcol + 1);
+      for (size_t k = 0; k < out_cols.size (); k++) {
+         const int c = out_cols[k];
+         meta_s[3 * k] = blk_start_loc[c + 1] - blk_start_loc[c];
+         meta_s[3 * k + 1] = o.col_i[c];
+         meta_s[3 * k + 2] = o.col_j[c];
+      }
+      XCHG (meta_s.data (), give3.data (), meta_r.data (), need3.data (), "overlap column");
+      // sanity of what arrived: ascending rows, every originally needed row present, lengths adding up
+      {
+         int64_t sum = 0;
+         for (int64_t c = 0; c < n_hcol; c++) sum += meta_r[3 * (size_t) c];
+         bool good = sum == n_halo2;
+         for (int64_t k = 1; k < n_halo2 && good; k++) good = halo2[(size_t) k] > halo2[(size_t) k - 1];
+         for (int64_t k = 0; k < n_halo && good; k++) good = std::binary_search (halo2.begin (), halo2.begin () + n_halo2, halo_rows[(size_t) k]);
+         if (!good) return fail (NKP_ECOMM, "nkp_create_dist: the completed halo is inconsistent (a water column straddles two ranks?)");
+      }
+      // the SpMV addresses the completed halo from here on
+      for (int64_t r = 0; r < m_loc; r++)
+         for (int e = rowptr_loc[r]; e < rowptr_loc[r + 1]; e++) {
+            const int64_t g = colind_glob[e];
+            if (g >= fst_row && g < fst_row + m_loc) continue;
+            colind_ext[(size_t) e] = (int32_t) (m_loc + (std::lower_bound (halo2.begin (), halo2.begin () + n_halo2, (int32_t) g) - halo2.begin ()));
+         }
+      n_halo = n_halo2;
+      halo_rows.assign (halo2.begin (), halo2.begin () + n_halo2);
+      halo_rows.push_back (0);
+      need.assign (need_rows.begin (), need_rows.end ());
+      give.assign (give_rows.begin (), give_rows.end ());
+      nsend = (int64_t) out_rows.size ();
+      send_rows.assign (out_rows.begin (), out_rows.end ());
+      send_rows.push_back (0);
+      // requester: which halo columns are lateral neighbours (position not owned here)
+      std::vector<int64_t> own_pos ((size_t) nblk_loc);
+      for (int64_t c = 0; c < nblk_loc; c++) own_pos[(size_t) c] = ((int64_t) o.col_j[c] << 32) | (uint32_t) o.col_i[c];
+      std::sort (own_pos.begin (), own_pos.end ());
+      std::vector<int32_t> flag_s ((size_t) n_hcol + 1, 0), flag_r (out_cols.size () + 1, 0);
+      std::vector<int> erow_need (P, 0), erow_give (P, 0);
+      {
+         size_t c = 0;
+         for (int p = 0; p < P; p++)
+            for (int k = 0; k < need_cols[p]; k++, c++) {
+               const int64_t key = ((int64_t) meta_r[3 * c + 2] << 32) | (uint32_t) meta_r[3 * c + 1];
+               flag_s[c] = std::binary_search (own_pos.begin (), own_pos.end (), key) ? 0 : 1;
+               if (flag_s[c]) erow_need[p] += meta_r[3 * c];
+            }
+      }
+      XCHG (flag_s.data (), need_cols.data (), flag_r.data (), give_cols.data (), "overlap selection");
+      // owner: ship the rows of the selected columns (entries per row, global columns, values as pairs of int32)
+      std::vector<int32_t> len_s, col_s, val_s;
+      std::vector<int> ent_give (P, 0), ent_need (P, 0), ent2_give (P, 0), ent2_need (P, 0);
+      {
+         size_t c = 0;
+         for (int p = 0; p < P; p++)
+            for (int k = 0; k < give_cols[p]; k++, c++) {
+               if (!flag_r[c]) continue;
+               const int col = out_cols[c];
+               for (int r = blk_start_loc[col]; r < blk_start_loc[col + 1]; r++) {
+                  len_s.push_back (rowptr_loc[r + 1] - rowptr_loc[r]);
+                  erow_give[p]++;
+                  for (int e = rowptr_loc[r]; e < rowptr_loc[r + 1]; e++) {
+                     col_s.push_back (colind_glob[e]);
+                     int32_t w[2];
+                     memcpy (w, &val[e], sizeof (double));
+                     val_s.push_back (w[0]);
+                     val_s.push_back (w[1]);
+                  }
+                  ent_give[p] += rowptr_loc[r + 1] - rowptr_loc[r];
+               }
+            }
+      }
+      int64_t n_erow = 0;
+      for (int p = 0; p < P; p++) n_erow += erow_need[p];
+      std::vector<int32_t> len_r ((size_t) n_erow + 1);
+      len_s.push_back (0);
+      XCHG (len_s.data (), erow_give.data (), len_r.data (), erow_need.data (), "overlap row length");
+      int64_t n_eent = 0;
+      {
+         size_t q = 0;
+         for (int p = 0; p < P; p++) {
+            int64_t t = 0;
+            for (int k = 0; k < erow_need[p]; k++, q++) t += len_r[q];
+            if (2 * t >= 2147483647LL || 2 * (int64_t) ent_give[p] >= 2147483647LL) return fail (NKP_EINVAL, "nkp_create_dist: overlap rows exceed the int32 exchange counts");
+            ent_need[p] = (int) t;
+            n_eent += t;
+         }
+         for (int p = 0; p < P; p++) { ent2_give[p] = 2 * ent_give[p]; ent2_need[p] = 2 * ent_need[p]; }
+      }
+      std::vector<int32_t> col_r ((size_t) n_eent + 1), val_r (2 * (size_t) n_eent + 2);
+      col_s.push_back (0);
+      val_s.push_back (0);
+      XCHG (col_s.data (), ent_give.data (), col_r.data (), ent_need.data (), "overlap column index");
+      XCHG (val_s.data (), ent2_give.data (), val_r.data (), ent2_need.data (), "overlap value");
+#undef XCHG
+      // ---- the matrix of the hierarchy: own rows, then the selected halo rows; columns renumbered, everything else dropped
+      std::vector<int32_t> sel_of_hpos ((size_t) n_halo2 + 1, -1);
+      e_blk.assign (blk_start_loc, blk_start_loc + nblk_loc + 1);
+      e_ci.assign (o.col_i, o.col_i + nblk_loc);
+      e_cj.assign (o.col_j, o.col_j + nblk_loc);
+      {
+         const int64_t per = (coupled_tracer_cnt > 1 && nblk_loc % coupled_tracer_cnt == 0) ? nblk_loc / coupled_tracer_cnt : nblk_loc;
+         e_ct.resize ((size_t) nblk_loc);
+         for (int64_t c = 0; c < nblk_loc; c++) e_ct[(size_t) c] = (int32_t) (c / per);
+      }
+      std::vector<int32_t> selcol_of_hpos ((size_t) n_halo2 + 1, -1);
+      {
+         int64_t hpos = 0;
+         for (int64_t c = 0; c < n_hcol; c++) {
+            const int len = meta_r[3 * (size_t) c];
+            if (flag_s[(size_t) c]) {
+               for (int k = 0; k < len; k++) {
+                  sel_of_hpos[(size_t) (hpos + k)] = (int32_t) n_sel++;
+                  selcol_of_hpos[(size_t) (hpos + k)] = (int32_t) e_ci.size ();
+                  sel_hpos.push_back ((int32_t) (hpos + k));
+               }
+               e_blk.push_back ((int32_t) (m_loc + n_sel));
+               e_ci.push_back (meta_r[3 * (size_t) c + 1]);
+               e_cj.push_back (meta_r[3 * (size_t) c + 2]);
+               e_ct.push_back (0);
+            }
+            hpos += len;
+         }
+      }
+      if (n_sel != n_erow) return fail (NKP_ECOMM, "nkp_create_dist: overlap rows announced and received differ");
+      auto ext_of_global = [&] (int64_t g) -> int64_t {
+         if (g >= fst_row && g < fst_row + m_loc) return g - fst_row;
+         const auto it = std::lower_bound (halo2.begin (), halo2.begin () + n_halo2, (int32_t) g);
+         if (it == halo2.begin () + n_halo2 || *it != (int32_t) g) return -1;
+         const int32_t q = sel_of_hpos[(size_t) (it - halo2.begin ())];
+         return q < 0 ? -1 : m_loc + q;
+      };
+      e_rowptr.assign ((size_t) (m_loc + n_sel) + 1, 0);
+      e_colind.reserve ((size_t) (nnz_loc + n_eent));
+      e_val.reserve ((size_t) (nnz_loc + n_eent));
+      std::vector<std::pair<int32_t, double>> rowbuf;
+      auto flush_row = [&] (int64_t r) {
+         bool sorted = true;
+         for (size_t k = 1; k < rowbuf.size () && sorted; k++) sorted = rowbuf[k].first > rowbuf[k - 1].first;
+         if (!sorted) std::sort (rowbuf.begin (), rowbuf.end (), [] (const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &b) { return a.first < b.first; });
+         for (const auto &pr : rowbuf) { e_colind.push_back (pr.first); e_val.push_back (pr.second); }
+         e_rowptr[(size_t) r + 1] = (int32_t) e_colind.size ();
+         rowbuf.clear ();
+      };
+      for (int64_t r = 0; r < m_loc; r++) {
+         for (int e = rowptr_loc[r]; e < rowptr_loc[r + 1]; e++) {
+            const int32_t x = colind_ext[(size_t) e];
+            if (x < m_loc) rowbuf.push_back ({ x, val[e] });
+            else {
+               const int32_t q = sel_of_hpos[(size_t) (x - m_loc)];
+               if (q >= 0) {
+                  rowbuf.push_back ({ (int32_t) (m_loc + q), val[e] });
+                  e_ct[(size_t) selcol_of_hpos[(size_t) (x - m_loc)]] = e_ct[(size_t) col_of[(size_t) r]];   // an overlap column carries the tracer of the rows that see it
+               }
+            }
+         }
+         flush_row (r);
+      }
+      {
+         size_t q = 0;
+         for (int64_t k = 0; k < n_sel; k++) {
+            for (int t = 0; t < len_r[(size_t) k]; t++, q++) {
+               const int64_t x = ext_of_global (col_r[q]);
+               if (x < 0) continue;
+               double v;
+               memcpy (&v, &val_r[2 * q], sizeof (double));
+               rowbuf.push_back ({ (int32_t) x, v });
+            }
+            flush_row (m_loc + k);
+         }
+      }
+      // overlap is worth its exchange only if some rank has any: same decision everywhere
+      std::vector<int64_t> all (P + 1, 0);
+      if (comm->allgather_i64_host (comm->ctx, n_sel, all.data ())) return fail (NKP_ECOMM, "nkp_create_dist: allgather failed");
+      for (int p = 0; p < P; p++) ras = ras || all[p] > 0;
+   }
+
+   // diagonal block: what the create path validates and what the hierarchy is built from without overlap
    std::vector<int32_t> drow ((size_t) m_loc + 1, 0), dcol;
    std::vector<double> dval;
    dcol.reserve ((size_t) nnz_loc);
@@ -1155,12 +1423,9 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
       drow[r + 1] = (int32_t) dcol.size ();
    }
    SpmvMatrixHost M = { nnz_loc, m_loc + n_halo, rowptr_loc, colind_ext.data (), val };
-   nkp_options o;
-   if (opt) o = *opt;
-   else nkp_default_options (&o);
-   o.rank = rank;
+   PrecondMatrixHost PM = { m_loc + n_sel, (int64_t) e_blk.size () - 1, e_rowptr.data (), e_colind.data (), e_val.data (), e_blk.data (), e_ci.data (), e_cj.data (), e_ct.data () };
    nkp_solver *s = nullptr;
-   rc = create_impl (&s, &o, m_loc, (int64_t) dcol.size (), drow.data (), dcol.data (), dval.data (), blk_start_loc, nblk_loc, coupled_tracer_cnt, &M);
+   rc = create_impl (&s, &o, m_loc, (int64_t) dcol.size (), drow.data (), dcol.data (), dval.data (), blk_start_loc, nblk_loc, coupled_tracer_cnt, &M, ras ? &PM : nullptr);
    // every rank must reach the collectives below even if its own setup failed: agree on success first
    {
       int64_t flag = rc ? 1 : 0;
@@ -1182,6 +1447,14 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
    bool ok = dev_alloc (s, &s->dist.send_idx, (size_t) nsend) == NKP_OK && dev_alloc (s, &s->dist.sendbuf, (size_t) nsend) == NKP_OK &&
              dev_alloc (s, &s->dist.xe, (size_t) (m_loc + n_halo)) == NKP_OK;
    if (ok && nsend) ok = hipMemcpy (s->dist.send_idx, send_rows.data (), (size_t) nsend * sizeof (int), hipMemcpyHostToDevice) == hipSuccess;
+   if (ok && ras) {
+      s->dist.n_sel = n_sel;
+      s->dist.n_ext = m_loc + n_sel;
+      ok = dev_alloc (s, &s->dist.sel_idx, (size_t) n_sel) == NKP_OK && dev_alloc (s, &s->dist.rext, (size_t) (m_loc + n_sel)) == NKP_OK &&
+           dev_alloc (s, &s->dist.zext, (size_t) (m_loc + n_sel)) == NKP_OK;
+      if (ok && n_sel) ok = hipMemcpy (s->dist.sel_idx, sel_hpos.data (), (size_t) n_sel * sizeof (int), hipMemcpyHostToDevice) == hipSuccess;
+      s->dist.ras = ok;
+   }
    if (!ok) { solver_free (s); return fail (NKP_ENOMEM, "nkp_create_dist: halo buffers could not be allocated"); }
    {
       const char *e = getenv ("NKP_DIST_OVERLAP");
@@ -1195,8 +1468,8 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
    s->dist.on = true;
    msg (s, 1, "nkp_create_dist: %d of %d SpMV row blocks are interior (multiplied while the halo travels: %s)\n", s->dist.seg_rb[2] - s->dist.seg_rb[1],
         s->dist.seg_rb[3], s->dist.overlap ? "yes" : "no");
-   msg (s, 1, "nkp_create_dist: rows [%lld, %lld) of %lld, %lld halo rows in, %lld rows out\n", (long long) fst_row,
-        (long long) (fst_row + m_loc), (long long) n_global, (long long) n_halo, (long long) nsend);
+   msg (s, 1, "nkp_create_dist: rows [%lld, %lld) of %lld, %lld halo rows in, %lld rows out; overlap (restricted additive Schwarz): %s, %lld rows of other ranks in this rank's hierarchy\n",
+        (long long) fst_row, (long long) (fst_row + m_loc), (long long) n_global, (long long) n_halo, (long long) nsend, s->dist.ras ? "on" : "off", (long long) s->dist.n_sel);
    *out = s;
    return NKP_OK;
 }

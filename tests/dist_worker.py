@@ -77,6 +77,8 @@ def main():
         # stream the library passes to the callback (the wrapper must not depend on the caller)
         result["dist_overlap"] = s.get_int("dist_overlap")
         result["interior_rowblocks"] = s.get_int("dist_interior_rowblocks")
+        result["ras"] = s.get_int("dist_ras")
+        result["ras_rows"] = s.get_int("dist_ras_rows")
         y_loc = s.spmv(xg[f:f + m])
         y_ref = ora.spmv(p.rowptr, p.colind, p.nzval, xg)[f:f + m]
         result["spmv_bit_exact"] = bool(np.array_equal(y_loc, y_ref))

@@ -22,12 +22,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(world, mode, out, extra=()):
+def launch(world, mode, out, extra=(), env_extra=None):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), "--mode", mode, "--out", out, *extra],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]

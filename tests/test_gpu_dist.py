@@ -18,6 +18,11 @@ def test_distributed_solve(tmp_path, world):
     assert len({r["iters"] for r in res}) == 1                  # every rank took the same global decisions
     # latitude bands: most rows have no off-rank column, their SpMV runs while the halo travels on a second stream
     assert all(r["dist_overlap"] == 1 and r["interior_rowblocks"] > 0 for r in res), res
+    # and every rank's hierarchy covers one ring of its neighbours' water columns (restricted additive Schwarz)
+    assert all(r["ras"] == 1 and r["ras_rows"] > 0 for r in res), res
+    plain = launch(world, "gpu-solve", str(tmp_path / "solve_plain"), extra=("--grid", "40x46x20"), env_extra={"NKP_DIST_RAS": "0"})
+    assert all(r["ras"] == 0 and r["status"] == 0 for r in plain), plain
+    assert res[0]["iters"] <= plain[0]["iters"], (res[0]["iters"], plain[0]["iters"])     # the overlap is there to save iterations
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -32,6 +37,8 @@ def test_distributed_solve_one_tracer_per_rank(tmp_path, world):
     assert len({r["iters"] for r in res}) == 1
     # every row couples to the other tracers' copy of its cell: no interior rows, nothing to overlap
     assert all(r["dist_overlap"] == 0 for r in res), res
+    # the other tracers' columns sit at positions this rank owns: they are not lateral neighbours, the hierarchy stays rank-local
+    assert all(r["ras"] == 0 and r["ras_rows"] == 0 for r in res), res
 
 
 def test_solve_ABdist_cli_with_builtin_rccl(tmp_path, golden_by_name):
