@@ -12,9 +12,10 @@ it the tensor is indefinite, which no ocean model produces); the round-1 recipe 
 (`round1_recipe` in the JSON line, never as `value`).
 
 N > 1 (one process per GPU, launched by torch.distributed.run, RCCL through torch.distributed), `--multi-gpu`:
-  c4 (default)  BASELINE configs[3]: the 1 degree x 60 x 4-tracer coupled Jacobian (n = 16.9 M), rows split over the N
-                ranks by the reference's contiguous row-block rule (src/solve_ABdist.c:141-144) snapped to water
-                columns: N = 2 -> two tracers per rank, 4 -> one tracer, 8 -> half a tracer (a latitude band) per rank
+  c4 (default)  BASELINE configs[3]: the 1 degree x 60 x 4-tracer coupled Jacobian (n = 16.9 M), renumbered cell-major
+                 and split over the N ranks by the reference's contiguous row-block rule
+                (src/solve_ABdist.c:141-144) snapped to whole cells: every rank holds a latitude band of all four tracers
+                (--c4-order tracer: the reference's tracer-major rows, N = 2 -> two tracers per rank, 4 -> one, 8 -> half)
   weak          the N-tracer coupled system, one tracer per rank (per-GPU work = the N = 1 workload)
   strong        the single-tracer matrix (or --grid 1440x720x80 = configs[4]) cut into N latitude bands
 
@@ -63,6 +64,8 @@ def parse():
                     help="N = 1 extra (reported beside `value`, never as `value`): that many right-hand sides in flight at once "
                          "on clones of the solver (nkp_clone), the reference's RHS loop run concurrently; 0 disables")
     ap.add_argument("--force-dist", action="store_true", help="developer switch: run the distributed code path even with one rank")
+    ap.add_argument("--c4-order", choices=["cell", "tracer"], default="cell",
+                    help="--multi-gpu c4: renumber the coupled system cell-major before cutting it (default), or cut the reference's tracer-major rows")
     ap.add_argument("--comm", choices=["rccl", "torch"], default="rccl",
                     help="N > 1 collectives: rccl = the library's own RCCL communicator (C only, no Python per iteration; "
                          "torch.distributed just carries the unique id), torch = torch.distributed callbacks")
@@ -217,22 +220,31 @@ def main():
         # through torch.distributed's RCCL communicator, multilevel hierarchy per rank with one ring of the neighbours' water columns where the cut is lateral (restricted additive Schwarz).
         try:
             if a.multi_gpu == "c4":
-                # BASELINE configs[3]: 4 coupled tracers, tracer-major rows (src/matrix.c:778-784); the n/P rule gives a rank
-                # 4/P tracers (P <= 4) or a latitude band of one tracer (P = 8)
+                # BASELINE configs[3]: 4 coupled tracers.  The reference stores them tracer-major (src/matrix.c:778-784), where
+                # its contiguous row blocks (src/solve_ABdist.c:141-144) put the same-cell couplings off-rank in every row; the
+                # rows are renumbered cell-major first, so the same rule cuts latitude bands of the whole
+                # coupled system: couplings rank-local, halo = the band edge (--c4-order tracer keeps the tracer-major cut)
                 tracers_global = 4
-                if 4 % world != 0 and world % 4 != 0:
-                    raise ValueError(f"configs[3] splits 4 tracers over 1, 2, 4, 8, ... ranks, not {world} (a rank would hold parts of two tracers)")
                 p4 = synth.generate(imt=imt, jmt=jmt, km=km, adv=a.adv, hmix=a.hmix, seed=0, isop_k33=k33, coupled_tracer_cnt=4)
                 blk4 = solver.column_blocks(p4.col_start(), p4.tracer_state_len, 4)
                 ci4, cj4 = solver.column_coords(p4.ind_i, p4.ind_j, p4.col_start(), 4)
-                starts = nd.snap_partition(blk4, world)
-                loc = nd.local_slice(p4.rowptr, p4.colind, p4.nzval, blk4, starts, rank, ci4, cj4)
                 n_global, nnz_global = p4.flat_len, p4.nnz
-                cnt_loc = max(1, 4 // world)
+                if a.c4_order == "cell":
+                    loc, starts, _ = nd.cell_major_slice(p4.rowptr, p4.colind, p4.nzval, blk4, 4, world, rank, ci4, cj4)
+                    cnt_loc = 4
+                    mode = (f"configs[3]: 4-tracer coupled system ({n_global} rows) renumbered cell-major and split into {world} contiguous row blocks "
+                            f"(a latitude band of all four tracers per GPU), halo alltoallv + allreduce over RCCL (torch.distributed), "
+                            f"multilevel hierarchy per rank with one ring of the neighbours' water columns where the cut is lateral (restricted additive Schwarz)")
+                else:
+                    if 4 % world != 0 and world % 4 != 0:
+                        raise ValueError(f"tracer-major configs[3] splits 4 tracers over 1, 2, 4, 8, ... ranks, not {world} (a rank would hold parts of two tracers)")
+                    starts = nd.snap_partition(blk4, world)
+                    loc = nd.local_slice(p4.rowptr, p4.colind, p4.nzval, blk4, starts, rank, ci4, cj4)
+                    cnt_loc = max(1, 4 // world)
+                    mode = (f"configs[3]: 4-tracer coupled system ({n_global} rows), tracer-major, split into {world} contiguous row blocks "
+                            f"({'%d tracer(s)' % (4 // world) if world <= 4 else 'a latitude band of one tracer'} per GPU), halo alltoallv + "
+                            f"allreduce over RCCL (torch.distributed), multilevel hierarchy per rank with one ring of the neighbours' water columns where the cut is lateral (restricted additive Schwarz)")
                 del p4
-                mode = (f"configs[3]: 4-tracer coupled system ({n_global} rows) split into {world} contiguous row blocks "
-                        f"({'%d tracer(s)' % (4 // world) if world <= 4 else 'a latitude band of one tracer'} per GPU), halo alltoallv + "
-                        f"allreduce over RCCL (torch.distributed), multilevel hierarchy per rank with one ring of the neighbours' water columns where the cut is lateral (restricted additive Schwarz)")
             elif a.multi_gpu == "weak":
                 tracers_global = world
                 cnt_loc = 1
@@ -411,6 +423,8 @@ def main():
                   "relres_checked_with_torch": relres_check, "setup_s": t_setup, "generate_s": t_gen,
                   "levels": s.get_int("levels"), "precond_cycles_per_iteration": s.get_int("precond_steps"),
                   "device_MB": s.get_int("device_bytes") / 1e6,
+                  "distributed": ({"halo_hidden_behind_interior_rows": s.get_int("dist_overlap"), "hierarchy_overlaps_neighbours": s.get_int("dist_ras"),
+                                   "overlap_rows_rank0": s.get_int("dist_ras_rows")} if distributed else None),
                   "precond_apply_ms": pre_ms, "krylov_iteration_ms": it_ms},
         "roofline": {"kernel": "csr_spmv_pipe_kernel<0, double, false>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -96,6 +96,10 @@ typedef struct nkp_options {
     * during nkp_create only. */
    const int32_t *col_i;
    const int32_t *col_j;
+   /* optional: tracer of every water-column block (nblk entries).  NULL = tracer-major rows (reference
+    * src/matrix.c:778-784): block c belongs to tracer c / (nblk / coupled_tracer_cnt).  Needed when the rows were
+    * reordered cell-major (nkp_cell_major_order below).  Columns of different tracers are never aggregated together. */
+   const int32_t *col_t;
 } nkp_options;
 
 int nkp_default_options (nkp_options *opt);
@@ -216,6 +220,22 @@ int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global,
                      const int32_t *colind_glob, const double *val,
                      const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt,
                      const nkp_comm_ops *comm);
+
+/* Cell-major ordering of a coupled system.  The reference stores coupled tracers tracer-major
+ * (src/matrix.c:778-784): cutting such a system into contiguous row blocks (src/solve_ABdist.c:141-144) puts the
+ * same-cell coupling entries (src/matrix.c:955-961) off-rank in EVERY row.  In cell-major order -- for every water-column
+ * position the columns of all tracers one after the other -- the same contiguous blocks are latitude bands of the whole
+ * coupled system, the couplings are rank-local and the halo is the band edge.  Host only, no GPU needed.
+ *   nkp_cell_major_order: blk_start[nblk+1] = tracer-major block offsets, nblk = cnt * (blocks per tracer), every tracer
+ *     with the same block lengths.  Out: perm[n] (new row -> old row), blk_start_new[nblk+1], col_t[nblk] (tracer of
+ *     every new block), col_src[nblk] (old block of every new block: col_i_new[c] = col_i[col_src[c]]).
+ *   nkp_permuted_rows: rows [r0, r1) of P A P^T (new numbering on both sides) from the tracer-major CSR; inv[n] = old row
+ *     -> new row.  rowptr_loc[r1 - r0 + 1] rebased to 0; colind_loc / val_loc sized for the entries of those rows, columns
+ *     sorted ascending within a row. */
+int nkp_cell_major_order (int64_t nblk, const int32_t *blk_start, int cnt, int32_t *perm, int32_t *blk_start_new,
+                          int32_t *col_t, int32_t *col_src);
+int nkp_permuted_rows (int64_t n, const int32_t *rowptr, const int32_t *colind, const double *val, const int32_t *perm,
+                       const int32_t *inv, int64_t r0, int64_t r1, int32_t *rowptr_loc, int32_t *colind_loc, double *val_loc);
 
 /* Multi-RHS concurrency: the reference solves its right-hand sides one after the other
  * against one factorisation (RHS loop, src/solve_ABglobal.c:370-409).  nkp_clone gives a second set of work

@@ -282,6 +282,10 @@ int main (int argc, char *argv[])
    memset (&ops, 0, sizeof ops);
    int info = 0;
    int file_transport = 0;
+   // coupled tracers over several ranks are solved in cell-major order (NKP_CELL_MAJOR=0: the file's tracer-major rows)
+   int32_t *cm_perm = NULL;                         // new row -> row of the file
+   bool cell_major = use_comm && world > 1 && coupled_tracer_cnt > 1 && nblk % coupled_tracer_cnt == 0;
+   { const char *e = getenv ("NKP_CELL_MAJOR"); if (e && atoi (e) == 0) cell_major = false; }
    if (use_comm) {
       // transport: RCCL (one GPU per rank; the unique id travels through NKP_RCCL_ID_FILE) or, for boxes with fewer GPUs
       // than ranks, the host-staged file transport (NKP_COMM=file, NKP_COMM_DIR=<directory every rank can write>)
@@ -356,9 +360,61 @@ int main (int argc, char *argv[])
          }
          if (iam == 0) (void) unlink (idfile);
       }
-      nkp_rowblock_partition_snapped (blk_start, nblk, world, iam, &fst_row, &m_loc, &fst_blk, &nblk_loc);
+      if (!cell_major) nkp_rowblock_partition_snapped (blk_start, nblk, world, iam, &fst_row, &m_loc, &fst_blk, &nblk_loc);
    }
-   {
+   if (cell_major) {
+      // Coupled tracers over several ranks: the file's rows are tracer-major (src/matrix.c:778-784), so the reference's
+      // contiguous row blocks would put the same-cell couplings (:955-961) off-rank in every row.  Renumber cell-major
+      // (nkp_cell_major_order) and cut by the same rule between whole cells: every rank gets a latitude band of all tracers.
+      const size_t nb = (size_t) nblk, nrow = (size_t) flat_len;
+      cm_perm = (int32_t *) malloc ((nrow ? nrow : 1) * sizeof (int32_t));
+      int32_t *inv = (int32_t *) malloc ((nrow ? nrow : 1) * sizeof (int32_t));
+      int32_t *blk_new = (int32_t *) malloc ((nb + 1) * sizeof (int32_t));
+      int32_t *col_t = (int32_t *) malloc ((nb ? nb : 1) * sizeof (int32_t));
+      int32_t *col_src = (int32_t *) malloc ((nb ? nb : 1) * sizeof (int32_t));
+      const int per = nblk / coupled_tracer_cnt;
+      int_t *cell_start = (int_t *) malloc (((size_t) per + 1) * sizeof (int_t));
+      if (!cm_perm || !inv || !blk_new || !col_t || !col_src || !cell_start) {
+         fprintf (stderr, "(%d) malloc failed in %s for the cell-major ordering\n", iam, argv[0]);
+         exit (EXIT_FAILURE);
+      }
+      if (nkp_cell_major_order (nblk, blk_start, coupled_tracer_cnt, cm_perm, blk_new, col_t, col_src)) {
+         fprintf (stderr, "(%d) %s\n", iam, nkp_last_error ());
+         exit (EXIT_FAILURE);
+      }
+      for (int r = 0; r < flat_len; r++) inv[cm_perm[r]] = r;
+      for (int c = 0; c <= per; c++) cell_start[c] = blk_new[(size_t) c * coupled_tracer_cnt];
+      int fst_cell = 0, ncell_loc = 0;
+      nkp_rowblock_partition_snapped (cell_start, per, world, iam, &fst_row, &m_loc, &fst_cell, &ncell_loc);
+      fst_blk = fst_cell * coupled_tracer_cnt;
+      nblk_loc = ncell_loc * coupled_tracer_cnt;
+      long long nnz_loc = 0;
+      for (int r = fst_row; r < fst_row + m_loc; r++) nnz_loc += rowptr[cm_perm[r] + 1] - rowptr[cm_perm[r]];
+      int_t *rowptr_loc = (int_t *) malloc ((size_t) (m_loc + 1) * sizeof (int_t));
+      int_t *colind_loc = (int_t *) malloc ((size_t) (nnz_loc ? nnz_loc : 1) * sizeof (int_t));
+      double *val_loc = (double *) malloc ((size_t) (nnz_loc ? nnz_loc : 1) * sizeof (double));
+      int_t *blk_loc = (int_t *) malloc ((size_t) (nblk_loc + 1) * sizeof (int_t));
+      int *ci_loc = (int *) malloc ((size_t) (nblk_loc ? nblk_loc : 1) * sizeof (int));
+      int *cj_loc = (int *) malloc ((size_t) (nblk_loc ? nblk_loc : 1) * sizeof (int));
+      if (!rowptr_loc || !colind_loc || !val_loc || !blk_loc || !ci_loc || !cj_loc) {
+         fprintf (stderr, "(%d) malloc failed in %s for the local row block\n", iam, argv[0]);
+         exit (EXIT_FAILURE);
+      }
+      if (nkp_permuted_rows (flat_len, rowptr, colind, nzval_row_wise, cm_perm, inv, fst_row, fst_row + m_loc, rowptr_loc, colind_loc, val_loc)) {
+         fprintf (stderr, "(%d) %s\n", iam, nkp_last_error ());
+         exit (EXIT_FAILURE);
+      }
+      for (int b = 0; b <= nblk_loc; b++) blk_loc[b] = blk_new[fst_blk + b] - fst_row;
+      for (int b = 0; b < nblk_loc; b++) { ci_loc[b] = col_i[col_src[fst_blk + b]]; cj_loc[b] = col_j[col_src[fst_blk + b]]; }
+      opt.col_i = ci_loc;
+      opt.col_j = cj_loc;
+      opt.col_t = col_t + fst_blk;
+      if (dbg_lvl)
+         printf ("(%d) cell-major order: cells %d..%d of %d, fst_row, flat_len_loc, nnz_loc = %d, %d, %lld\n", iam, fst_cell, fst_cell + ncell_loc, per, fst_row, m_loc, nnz_loc);
+      info = nkp_create_dist (&solver, &opt, flat_len, fst_row, m_loc, nnz_loc, rowptr_loc, colind_loc, val_loc, blk_loc, nblk_loc, coupled_tracer_cnt, &ops);
+      free (rowptr_loc); free (colind_loc); free (val_loc); free (blk_loc); free (ci_loc); free (cj_loc);
+      free (inv); free (blk_new); free (col_t); free (col_src); free (cell_start);
+   } else {
       int_t *rowptr_loc = (int_t *) malloc ((size_t) (m_loc + 1) * sizeof (int_t));
       int_t *blk_loc = (int_t *) malloc ((size_t) (nblk_loc + 1) * sizeof (int_t));
       if (rowptr_loc == NULL || blk_loc == NULL) {
@@ -488,6 +544,15 @@ int main (int argc, char *argv[])
          }
          if (get_B_global (vars_per_solve, B))
             exit (EXIT_FAILURE);
+#ifdef NKP_DIST
+         if (cm_perm) {                                  // the solver's rows are in cell-major order
+            double *T = (double *) malloc ((size_t) (flat_len ? flat_len : 1) * sizeof (double));
+            if (T == NULL) { fprintf (stderr, "(%d) malloc failed in %s for the reordered B\n", iam, argv[0]); exit (EXIT_FAILURE); }
+            for (int r = 0; r < flat_len; r++) T[r] = B[cm_perm[r]];
+            memcpy (B, T, (size_t) flat_len * sizeof (double));
+            free (T);
+         }
+#endif
 
          double berr = 0.0, relres = 0.0;
          int iters = 0;
@@ -511,6 +576,11 @@ int main (int argc, char *argv[])
                exit (EXIT_FAILURE);
             }
             if (iam == 0) {
+#ifdef NKP_DIST
+               if (cm_perm)
+                  for (int r = 0; r < flat_len; r++) B[cm_perm[r]] = X[r];       // back to the file's tracer-major order
+               else
+#endif
                memcpy (B, X, (size_t) flat_len * sizeof (double));
                free (X);
             }

@@ -503,7 +503,7 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
       const int coarsest_rows = getenv ("NKP_ML_COARSEST_ROWS") ? atoi (getenv ("NKP_ML_COARSEST_ROWS")) : 3000;   // dense inverse on the device: one tiny level less at 3 degrees, cycle 1.15 -> 0.96 ms
       const int mrc = pm ? ml_setup (s->ml, pm->n, pm->rowptr, pm->colind, pm->val, pm->blk_start, pm->nblk, pm->col_i, pm->col_j, pm->col_t, coupled_tracer_cnt, opt.ml_levels,
                                      opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err)
-                         : ml_setup (s->ml, n, rowptr, colind, val, blk_start, nblk, blk_default.empty () ? opt.col_i : nullptr, blk_default.empty () ? opt.col_j : nullptr, nullptr,
+                         : ml_setup (s->ml, n, rowptr, colind, val, blk_start, nblk, blk_default.empty () ? opt.col_i : nullptr, blk_default.empty () ? opt.col_j : nullptr, blk_default.empty () ? opt.col_t : nullptr,
                                      coupled_tracer_cnt, opt.ml_levels, opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err);
       if (mrc != 0) {
          rc = fail (mrc, "nkp_create: %s", err);
@@ -1338,7 +1338,7 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
       {
          const int64_t per = (coupled_tracer_cnt > 1 && nblk_loc % coupled_tracer_cnt == 0) ? nblk_loc / coupled_tracer_cnt : nblk_loc;
          e_ct.resize ((size_t) nblk_loc);
-         for (int64_t c = 0; c < nblk_loc; c++) e_ct[(size_t) c] = (int32_t) (c / per);
+         for (int64_t c = 0; c < nblk_loc; c++) e_ct[(size_t) c] = o.col_t ? o.col_t[c] : (int32_t) (c / per);
       }
       std::vector<int32_t> selcol_of_hpos ((size_t) n_halo2 + 1, -1);
       {
@@ -1471,6 +1471,61 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
    msg (s, 1, "nkp_create_dist: rows [%lld, %lld) of %lld, %lld halo rows in, %lld rows out; overlap (restricted additive Schwarz): %s, %lld rows of other ranks in this rank's hierarchy\n",
         (long long) fst_row, (long long) (fst_row + m_loc), (long long) n_global, (long long) n_halo, (long long) nsend, s->dist.ras ? "on" : "off", (long long) s->dist.n_sel);
    *out = s;
+   return NKP_OK;
+}
+
+extern "C" int nkp_cell_major_order (int64_t nblk, const int32_t *blk_start, int cnt, int32_t *perm, int32_t *blk_start_new, int32_t *col_t, int32_t *col_src)
+{
+   if (!blk_start || !perm || !blk_start_new || !col_t || !col_src || cnt < 1 || nblk < 0 || nblk % cnt != 0)
+      return fail (NKP_EINVAL, "nkp_cell_major_order: bad arguments (nblk = %lld must be a multiple of the tracer count %d)", (long long) nblk, cnt);
+   const int64_t per = nblk / cnt;
+   const int64_t tsl = per ? blk_start[per] - blk_start[0] : 0;
+   for (int t = 1; t < cnt; t++)
+      for (int64_t c = 0; c <= per; c++)
+         if (blk_start[t * per + c] - blk_start[t * per] != blk_start[c] - blk_start[0])
+            return fail (NKP_EINVAL, "nkp_cell_major_order: tracer %d does not have the water columns of tracer 0 (block %lld)", t, (long long) c);
+   int64_t row = 0, b = 0;
+   blk_start_new[0] = 0;
+   for (int64_t c = 0; c < per; c++)
+      for (int t = 0; t < cnt; t++, b++) {
+         const int64_t old = t * per + c;
+         for (int r = blk_start[old]; r < blk_start[old + 1]; r++) perm[row++] = r;
+         blk_start_new[b + 1] = (int32_t) row;
+         col_t[b] = t;
+         col_src[b] = (int32_t) old;
+      }
+   (void) tsl;
+   return NKP_OK;
+}
+
+extern "C" int nkp_permuted_rows (int64_t n, const int32_t *rowptr, const int32_t *colind, const double *val, const int32_t *perm, const int32_t *inv,
+                                  int64_t r0, int64_t r1, int32_t *rowptr_loc, int32_t *colind_loc, double *val_loc)
+{
+   if (!rowptr || !perm || !inv || !rowptr_loc || r0 < 0 || r1 < r0 || r1 > n) return fail (NKP_EINVAL, "nkp_permuted_rows: bad arguments");
+   rowptr_loc[0] = 0;
+   for (int64_t r = r0; r < r1; r++) {
+      const int old = perm[r];
+      rowptr_loc[r - r0 + 1] = rowptr_loc[r - r0] + (rowptr[old + 1] - rowptr[old]);
+   }
+   const int nt = (r1 - r0 >= 200000) ? (int) std::min (16u, std::max (1u, std::thread::hardware_concurrency ())) : 1;
+   auto work = [&] (int t) {
+      std::vector<std::pair<int32_t, double>> buf;
+      const int64_t a = r0 + (r1 - r0) * t / nt, b = r0 + (r1 - r0) * (t + 1) / nt;
+      for (int64_t r = a; r < b; r++) {
+         const int old = perm[r];
+         buf.clear ();
+         for (int e = rowptr[old]; e < rowptr[old + 1]; e++) buf.push_back ({ inv[colind[e]], val[e] });
+         std::sort (buf.begin (), buf.end (), [] (const std::pair<int32_t, double> &x, const std::pair<int32_t, double> &y) { return x.first < y.first; });
+         int64_t o = rowptr_loc[r - r0];
+         for (const auto &pr : buf) { colind_loc[o] = pr.first; val_loc[o] = pr.second; o++; }
+      }
+   };
+   if (nt == 1) work (0);
+   else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nt; t++) pool.emplace_back (work, t);
+      for (std::thread &th : pool) th.join ();
+   }
    return NKP_OK;
 }
 

@@ -66,6 +66,26 @@ def tracer_slice(p1, rank, nranks):
     return loc, np.arange(nranks + 1, dtype=np.int64) * tsl, nranks * tsl
 
 
+def cell_major_slice(rowptr, colind, val, blk_start, coupled_tracer_cnt, nranks, rank, col_i=None, col_j=None):
+    """This rank's rows of a coupled system in CELL-MAJOR order: the tracer-major system
+    (reference src/matrix.c:778-784) is renumbered so that the columns of all tracers at one water-column position follow
+    each other, then cut by the reference's contiguous row-block rule (src/solve_ABdist.c:141-144).  The blocks are latitude
+    bands of the whole coupled system: the same-cell couplings stay on the rank, the halo is the band edge.
+    Returns (loc, starts, perm): loc as local_slice gives it (plus col_t), perm = new row -> old row (b_new = b_old[perm])."""
+    perm, inv, blk_new, col_t, col_src = _solver.cell_major_order(blk_start, coupled_tracer_cnt)
+    # cuts between cells, never between the tracers of one cell
+    starts = snap_partition(blk_new[::coupled_tracer_cnt], nranks)
+    f, e = int(starts[rank]), int(starts[rank + 1])
+    rp, ci, v = _solver.permuted_rows(rowptr, colind, val, perm, inv, f, e)
+    b0, b1 = int(np.searchsorted(blk_new, f)), int(np.searchsorted(blk_new, e))
+    loc = dict(rowptr=rp, colind=ci, val=v, blk_start=(blk_new[b0:b1 + 1].astype(np.int64) - f).astype(np.int32), fst_row=f, m_loc=e - f,
+               col_t=np.ascontiguousarray(col_t[b0:b1], np.int32))
+    if col_i is not None:
+        loc["col_i"] = np.ascontiguousarray(np.asarray(col_i)[col_src[b0:b1]], np.int32)
+        loc["col_j"] = np.ascontiguousarray(np.asarray(col_j)[col_src[b0:b1]], np.int32)
+    return loc, starts, perm
+
+
 def plan_host(rowptr_loc, colind_glob, starts, rank):
     """nkp_dist_plan_host: remapped columns, needed off-rank rows, per-owner counts (no GPU needed)."""
     lib = _solver.load_library()
@@ -312,9 +332,11 @@ class NkpDistSolver(_solver.NkpSolver):
         self._comm = comm                      # keeps the callbacks alive
         opt = _solver.default_options(**options)
         rp, ci, v, bs = loc["rowptr"], loc["colind"], loc["val"], loc["blk_start"]
-        self._keep = (rp, ci, v, bs, loc.get("col_i"), loc.get("col_j"))
+        self._keep = (rp, ci, v, bs, loc.get("col_i"), loc.get("col_j"), loc.get("col_t"))
         if loc.get("col_i") is not None:
             opt.col_i, opt.col_j = _solver._p(loc["col_i"], C.c_int32), _solver._p(loc["col_j"], C.c_int32)
+        if loc.get("col_t") is not None:
+            opt.col_t = _solver._p(loc["col_t"], C.c_int32)
         h = C.c_void_p()
         rc = lib.nkp_create_dist(C.byref(h), C.byref(opt), int(n_global), int(loc["fst_row"]), int(loc["m_loc"]), int(ci.size),
                                  _solver._p(rp, C.c_int32), _solver._p(ci, C.c_int32), _solver._p(v, C.c_double),

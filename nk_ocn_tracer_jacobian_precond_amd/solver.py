@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "nkp_get_int", "nkp_set_stream", "nkp_destroy", "nkp_last_error", "nkp_comm_unique_id",
     "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host", "nkp_set_device",
     "nkp_gather_root", "nkp_clone", "nkp_ml_plan_host", "nkp_comm_file_init", "nkp_comm_file_free",
-    "nkp_create64",
+    "nkp_create64", "nkp_cell_major_order", "nkp_permuted_rows",
 ]
 
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
@@ -48,7 +48,7 @@ class NkpOptions(C.Structure):
         ("max_iters", C.c_int), ("rtol", C.c_double), ("atol", C.c_double), ("device", C.c_int),
         ("verbose", C.c_int), ("rank", C.c_int), ("reorth", C.c_int), ("ml_levels", C.c_int),
         ("ml_smooth", C.c_int), ("basis_f32", C.c_int), ("precond_steps", C.c_int), ("equil", C.c_int), ("reserved", C.c_int * 4),
-        ("col_i", C.POINTER(C.c_int32)), ("col_j", C.POINTER(C.c_int32)),
+        ("col_i", C.POINTER(C.c_int32)), ("col_j", C.POINTER(C.c_int32)), ("col_t", C.POINTER(C.c_int32)),
     ]
 
 
@@ -154,10 +154,53 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+def cell_major_order(blk_start, coupled_tracer_cnt):
+    """nkp_cell_major_order (host only): the cell-major ordering of a tracer-major coupled system.  Returns
+    (perm new row -> old row, inv old row -> new row, blk_start_new, col_t, col_src)."""
+    lib = load_library()
+    blk = np.ascontiguousarray(blk_start, np.int32)
+    nblk, n = blk.size - 1, int(blk[-1])
+    perm = np.empty(max(n, 1), np.int32)
+    blk_new = np.empty(nblk + 1, np.int32)
+    col_t = np.empty(max(nblk, 1), np.int32)
+    col_src = np.empty(max(nblk, 1), np.int32)
+    lib.nkp_cell_major_order.argtypes = [C.c_int64, C.POINTER(C.c_int32), C.c_int] + [C.POINTER(C.c_int32)] * 4
+    rc = lib.nkp_cell_major_order(nblk, _p(blk, C.c_int32), int(coupled_tracer_cnt), _p(perm, C.c_int32), _p(blk_new, C.c_int32),
+                                  _p(col_t, C.c_int32), _p(col_src, C.c_int32))
+    if rc != 0:
+        raise NkpError(rc, lib.nkp_last_error().decode())
+    perm = perm[:n]
+    inv = np.empty(n, np.int32)
+    inv[perm] = np.arange(n, dtype=np.int32)
+    return perm, inv, blk_new, col_t[:nblk], col_src[:nblk]
+
+
+def permuted_rows(rowptr, colind, val, perm, inv, r0, r1):
+    """nkp_permuted_rows (host only): rows [r0, r1) of P A P^T as (rowptr rebased to 0, colind in the new numbering, val)."""
+    lib = load_library()
+    rowptr = np.ascontiguousarray(rowptr, np.int32)
+    colind = np.ascontiguousarray(colind, np.int32)
+    val = np.ascontiguousarray(val, np.float64)
+    perm = np.ascontiguousarray(perm, np.int32)
+    inv = np.ascontiguousarray(inv, np.int32)
+    old = perm[r0:r1]
+    nloc = int((rowptr[old.astype(np.int64) + 1].astype(np.int64) - rowptr[old]).sum())
+    rp = np.empty(r1 - r0 + 1, np.int32)
+    ci = np.empty(max(nloc, 1), np.int32)
+    v = np.empty(max(nloc, 1), np.float64)
+    lib.nkp_permuted_rows.argtypes = [C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    rc = lib.nkp_permuted_rows(rowptr.size - 1, _p(rowptr, C.c_int32), _p(colind, C.c_int32), _p(val, C.c_double), _p(perm, C.c_int32),
+                               _p(inv, C.c_int32), int(r0), int(r1), _p(rp, C.c_int32), _p(ci, C.c_int32), _p(v, C.c_double))
+    if rc != 0:
+        raise NkpError(rc, lib.nkp_last_error().decode())
+    return rp, ci[:nloc], v[:nloc]
+
+
 class NkpSolver:
     """Device-resident solver for one CSR matrix (setup = the reference's factor-only call)."""
 
-    def __init__(self, rowptr, colind, val, blk_start=None, coupled_tracer_cnt=1, col_i=None, col_j=None, **options):
+    def __init__(self, rowptr, colind, val, blk_start=None, coupled_tracer_cnt=1, col_i=None, col_j=None, col_t=None, **options):
         self._lib = load_library()
         self._h = C.c_void_p()
         # 64-bit row pointers (CDF-5 matrix files, callers counting entries in int64) go through nkp_create64
@@ -175,6 +218,11 @@ class NkpSolver:
             if blk_start is None or col_i.size != len(blk_start) - 1 or col_j.size != col_i.size:
                 raise ValueError("col_i / col_j need one entry per block of blk_start")
             opt.col_i, opt.col_j = _p(col_i, C.c_int32), _p(col_j, C.c_int32)
+        if col_t is not None:                                  # rows not tracer-major (cell_major_order): tracer of every block
+            col_t = np.ascontiguousarray(col_t, np.int32)
+            if blk_start is None or col_t.size != len(blk_start) - 1:
+                raise ValueError("col_t needs one entry per block of blk_start")
+            opt.col_t = _p(col_t, C.c_int32)
         if blk_start is not None:
             blk_start = np.ascontiguousarray(blk_start, np.int32)
             bp, nb = _p(blk_start, C.c_int32), blk_start.size - 1

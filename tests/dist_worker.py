@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--grid", default="24x20x10")
     ap.add_argument("--restart", type=int, default=60)
     ap.add_argument("--seed", type=int, default=5)
-    ap.add_argument("--partition", default="bands", help="bands: latitude bands of one matrix; tracers: one coupled tracer per rank")
+    ap.add_argument("--partition", default="bands", help="bands: latitude bands of one matrix; tracers: one coupled tracer per rank; "
+                    "cells: a 2-tracer coupled system in cell-major order, cut into bands of whole cells")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -40,6 +41,17 @@ def main():
     if a.partition == "tracers":
         loc, starts, n = nd.tracer_slice(p, rank, world)
         p = synth.generate(imt=imt, jmt=jmt, km=km, adv="upwind3", hmix="isop", seed=a.seed, coupled_tracer_cnt=world)   # global matrix: checks only
+    elif a.partition == "cells":
+        import types
+        cnt = 2
+        p2 = synth.generate(imt=imt, jmt=jmt, km=km, adv="upwind3", hmix="isop", seed=a.seed, coupled_tracer_cnt=cnt)
+        blk2 = solver.column_blocks(p2.col_start(), p2.tracer_state_len, cnt)
+        ci2, cj2 = solver.column_coords(p2.ind_i, p2.ind_j, p2.col_start(), cnt)
+        loc, starts, perm = nd.cell_major_slice(p2.rowptr, p2.colind, p2.nzval, blk2, cnt, world, rank, ci2, cj2)
+        n = p2.flat_len
+        A2 = p2.scipy_csr()[perm][:, perm].tocsr()          # the global matrix in the new numbering: checks only
+        A2.sort_indices()
+        p = types.SimpleNamespace(rowptr=A2.indptr.astype(np.int32), colind=A2.indices.astype(np.int32), nzval=A2.data)
     else:
         starts = nd.snap_partition(blk, world)
         loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, rank, ci, cj)

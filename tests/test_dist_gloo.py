@@ -129,3 +129,50 @@ def test_config3_partition_keeps_tracers_and_columns_whole(world):
         own_cells = np.unique(np.arange(f, f + m) % tsl)
         other = halo[(halo // tsl) != (f // tsl)] if world >= 4 else halo
         assert np.isin(other % tsl, own_cells).all() or world == 8                         # same-cell couplings only (bands add lateral halo)
+
+
+def test_cell_major_order_and_slices():
+    """SURVEY.md section 8e-2 (host part): the cell-major renumbering of a tracer-major coupled system is a permutation that
+    keeps water columns whole and puts the tracers of one cell next to each other; the rank slices of the permuted matrix,
+    stacked, are P A P^T; and a band of cells needs only the band edge from other ranks, not the other tracers' vectors."""
+    import scipy.sparse as sp
+    cnt = 3
+    p = synth.generate(imt=24, jmt=20, km=10, adv="upwind3", hmix="isop", seed=5, coupled_tracer_cnt=cnt)
+    blk = solver.column_blocks(p.col_start(), p.tracer_state_len, cnt)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), cnt)
+    perm, inv, blk_new, col_t, col_src = solver.cell_major_order(blk, cnt)
+    n = p.flat_len
+    assert np.array_equal(np.sort(perm), np.arange(n)) and np.array_equal(perm[inv], np.arange(n))
+    assert np.array_equal(col_t, np.tile(np.arange(cnt), (blk.size - 1) // cnt))
+    assert np.array_equal(np.diff(blk_new), np.diff(blk)[col_src])                 # whole columns, same lengths
+    per = (blk.size - 1) // cnt
+    assert np.array_equal(col_src.reshape(per, cnt), np.arange(per)[:, None] + per * np.arange(cnt)[None, :])
+    A = p.scipy_csr()
+    want = A[perm][:, perm].tocsr()
+    want.sort_indices()
+    P = 3
+    parts, halo_total, m_total = [], 0, 0
+    for r in range(P):
+        loc, starts, perm_r = nd.cell_major_slice(p.rowptr, p.colind, p.nzval, blk, cnt, P, r, ci, cj)
+        assert np.array_equal(perm_r, perm)
+        assert set(starts.tolist()) <= set(blk_new[::cnt].tolist())              # cuts between cells
+        assert np.array_equal(loc["col_t"], col_t[np.searchsorted(blk_new, starts[r]):np.searchsorted(blk_new, starts[r + 1])])
+        parts.append(sp.csr_matrix((loc["val"], loc["colind"], loc["rowptr"]), shape=(loc["m_loc"], n)))
+        ext, halo, need = nd.plan_host(loc["rowptr"], loc["colind"], starts, r)
+        halo_total += halo.size
+        m_total += loc["m_loc"]
+        # grid positions travel with the columns
+        assert np.array_equal(loc["col_i"], np.asarray(ci)[col_src][np.searchsorted(blk_new, starts[r]):np.searchsorted(blk_new, starts[r + 1])])
+    got = sp.vstack(parts).tocsr()
+    assert (got != want).nnz == 0
+    for r in range(got.shape[0]):
+        row = got.indices[got.indptr[r]:got.indptr[r + 1]]
+        assert np.all(np.diff(row) > 0)
+    assert m_total == n
+    # tracer-major blocks of the same system: every rank would need (cnt - 1) / cnt of the whole vector
+    tracer_major_halo = 0
+    st = nd.snap_partition(blk, P)
+    for r in range(P):
+        loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, st, r)
+        tracer_major_halo += nd.plan_host(loc["rowptr"], loc["colind"], st, r)[1].size
+    assert halo_total < 0.5 * tracer_major_halo, (halo_total, tracer_major_halo)

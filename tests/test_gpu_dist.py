@@ -96,6 +96,8 @@ def test_solve_ABdist_cli_multi_process(tmp_path, golden_by_name, world, case):
     assert sum("nkp_create_dist: rows [" in so for so, _ in outs) == world
     rows = sorted(int(so.split("nkp_create_dist: rows [")[1].split(",")[0]) for so, _ in outs)
     assert rows[0] == 0 and len(set(rows)) == world            # every rank owned a different row block
+    # a coupled pair over several ranks is solved in cell-major order (bands of whole cells) and written back tracer-major
+    assert all(("cell-major order" in so) == (g.cnt > 1) for so, _ in outs)
     out = nc3.NcFile(dst)
     for grp in g.groups():
         k = g.varnames.index(grp)
@@ -124,6 +126,23 @@ def test_stale_rccl_id_file_is_ignored(tmp_path, golden_by_name):
     assert not idfile.exists()                                  # rank 0 removed its id once the communicator existed
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_solve_cell_major_bands(tmp_path, world):
+    """a 2-tracer coupled system renumbered cell-major and cut into bands of whole cells -- the same-cell
+    couplings are rank-local (so is their share of the hierarchy: col_t keeps the tracers apart), the band edge is overlap."""
+    res = launch(world, "gpu-solve", str(tmp_path / "solve_c"), extra=("--grid", "40x46x20", "--partition", "cells"))
+    assert all(r["spmv_bit_exact"] for r in res), res
+    assert all(not r["comm_errors"] for r in res), res
+    assert all(r["status"] == 0 and r["relres"] <= 1e-10 for r in res), res
+    assert res[0]["relres_checked"] <= 1.1e-10
+    assert len({r["iters"] for r in res}) == 1
+    assert all(r["dist_overlap"] == 1 and r["ras"] == 1 and r["ras_rows"] > 0 for r in res), res
+    # the tracer-major cut of a coupled system (one tracer per rank) pays for ignoring the coupling in its preconditioner
+    if world == 2:
+        tm = launch(world, "gpu-solve", str(tmp_path / "solve_tm"), extra=("--grid", "40x46x20", "--partition", "tracers"))
+        assert res[0]["iters"] <= tm[0]["iters"], (res[0]["iters"], tm[0]["iters"])
+
+
 def test_bench_distributed_path_on_one_rank(tmp_path):
     """bench.py's N > 1 code path (configs[3] layout, library RCCL communicator after its pre-flight self-test, barriers,
     max-over-ranks timing) driven with a single rank: RCCL wants one GPU per rank and the test box has one."""
@@ -144,3 +163,26 @@ def test_bench_distributed_path_on_one_rank(tmp_path):
     assert "self-test" not in out.stderr, out.stderr[-2000:]
     assert line["value"] > 0 and max(line["solve"]["relres"]) <= 1e-10
     assert line["solve"]["relres_checked_with_torch"] <= 1.1e-10
+
+
+def test_cell_major_order_on_one_gpu():
+    """The hierarchy does not depend on tracer-major rows: the same coupled system renumbered cell-major (col_t names the
+    tracer of every column) is solved to the same x in about the same number of iterations."""
+    import numpy as np
+    from nk_ocn_tracer_jacobian_precond_amd import solver, synth
+    cnt = 2
+    p = synth.generate(imt=40, jmt=46, km=20, adv="upwind3", hmix="isop", seed=2, coupled_tracer_cnt=cnt)
+    blk = solver.column_blocks(p.col_start(), p.tracer_state_len, cnt)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), cnt)
+    b = np.random.default_rng(0).standard_normal(p.flat_len)
+    s0 = solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, coupled_tracer_cnt=cnt, col_i=ci, col_j=cj, rtol=1e-11)
+    x0, i0 = s0.solve(b)
+    s0.close()
+    perm, inv, blk_new, col_t, col_src = solver.cell_major_order(blk, cnt)
+    rp, cc, vv = solver.permuted_rows(p.rowptr, p.colind, p.nzval, perm, inv, 0, p.flat_len)
+    s1 = solver.NkpSolver(rp, cc, vv, blk_new, coupled_tracer_cnt=cnt, col_i=np.asarray(ci)[col_src], col_j=np.asarray(cj)[col_src], col_t=col_t, rtol=1e-11)
+    x1, i1 = s1.solve(b[perm])
+    s1.close()
+    assert i0["status"] == 0 and i1["status"] == 0
+    assert np.linalg.norm(x1[inv] - x0) <= 1e-8 * np.linalg.norm(x0)
+    assert abs(i1["iters"] - i0["iters"]) <= max(3, 0.2 * i0["iters"]), (i0["iters"], i1["iters"])
