@@ -253,6 +253,21 @@ int nkp_set_device (int device);
  * MPI_Send/MPI_Recv tag 4 (src/solve_ABdist.c:377, 406). */
 int nkp_gather_root (nkp_solver *s, const double *x_loc, double *x_global);
 
+/* The whole host-side plan of nkp_create_dist as an object, for tests without a GPU: collective over the ranks through the
+ * HOST callbacks of `comm` (alltoallv_i32_host, allgather_i64_host); no HIP call.  Fields (nkp_dist_plan_size gives the
+ * element count, nkp_dist_plan_copy copies): SpMV side -- "colind_ext" (int32, the local columns renumbered [own | halo]),
+ * "halo_rows" (global rows received before every SpMV; with grid positions in opt the halo is completed to whole water
+ * columns), "send_rows" (own rows sent, grouped by destination), "need" / "give" (per-rank counts); hierarchy side, filled
+ * when the overlap is on (nkp_dist_plan_size (p, "ras") == 1) -- the matrix on [own rows | overlap rows]: "rowptr",
+ * "colind", "val" (double), "blk_start", "col_i", "col_j", "col_t", and "sel_hpos" (position in the halo of every overlap row). */
+typedef struct nkp_dist_plan nkp_dist_plan;
+int nkp_dist_overlap_plan_host (nkp_dist_plan **out, const nkp_options *opt, int64_t n_global, int64_t fst_row, int64_t m_loc,
+                                int64_t nnz_loc, const int32_t *rowptr_loc, const int32_t *colind_glob, const double *val,
+                                const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt, const nkp_comm_ops *comm);
+int64_t nkp_dist_plan_size (const nkp_dist_plan *p, const char *what);
+int nkp_dist_plan_copy (const nkp_dist_plan *p, const char *what, void *dst);
+void nkp_dist_plan_free (nkp_dist_plan *p);
+
 /* Host-only planning step of nkp_create_dist, exposed so the partition / halo logic can be tested
  * without a GPU: given this rank's rows and the row offsets of all ranks (starts[nranks+1]),
  * writes the remapped column indices (local rows -> [0, m_loc), halo -> m_loc + position in the

@@ -1142,45 +1142,47 @@ extern "C" int nkp_dist_plan_host (int64_t m_loc, int64_t nnz_loc, const int32_t
    return NKP_OK;
 }
 
-extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global, int64_t fst_row, int64_t m_loc,
-                                int64_t nnz_loc, const int32_t *rowptr_loc, const int32_t *colind_glob, const double *val,
-                                const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt, const nkp_comm_ops *comm)
-{
-   if (!out) return fail (NKP_EINVAL, "nkp_create_dist: out is NULL");
-   *out = nullptr;
-   if (!comm || (comm->nranks <= 1 && !getenv ("NKP_FORCE_DIST"))) {
-      if (fst_row != 0 || m_loc != n_global) return fail (NKP_EINVAL, "nkp_create_dist: a single rank must own all rows");
-      return create_impl (out, opt, n_global, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt, nullptr);
-   }
-   if (!comm->allreduce || !comm->alltoallv || !comm->alltoallv_i32_host || !comm->allgather_i64_host)
-      return fail (NKP_EINVAL, "nkp_create_dist: incomplete nkp_comm_ops");
-   if (!rowptr_loc || m_loc < 0 || nnz_loc < 0 || (nnz_loc > 0 && (!colind_glob || !val))) return fail (NKP_EINVAL, "nkp_create_dist: bad matrix arguments");
-   const int P = comm->nranks, rank = comm->rank;
-   std::vector<int64_t> starts (P + 1, 0);
-   if (comm->allgather_i64_host (comm->ctx, fst_row, starts.data ())) return fail (NKP_ECOMM, "nkp_create_dist: allgather failed");
-   starts[P] = n_global;
-   for (int p = 0; p < P; p++)
-      if (starts[p + 1] < starts[p] || starts[0] != 0) return fail (NKP_EINVAL, "nkp_create_dist: row blocks must be contiguous and ascending over the ranks");
-   if (starts[rank + 1] - starts[rank] != m_loc) return fail (NKP_EINVAL, "nkp_create_dist: m_loc does not match the next rank's fst_row");
+// ---------------------------------------------------------------- host-side plan of the distributed flavour
+// Everything nkp_create_dist decides before a byte goes to the device: the halo of the SpMV, and -- with grid positions --
+// the overlap of the hierarchy (completed halo columns, which of them are lateral neighbours, their matrix rows fetched
+// from the owners).  Collective over the ranks through the host callbacks of nkp_comm_ops; no HIP call, so the N > 1 logic
+// is testable without a GPU (nkp_dist_overlap_plan_host, tests/test_dist_gloo.py).
+struct DistPlan {
+   std::vector<int32_t> colind_ext, halo_rows, send_rows, need, give;     // SpMV: renumbered columns, halo rows in, own rows out
+   int64_t n_halo = 0, nsend = 0;
+   std::vector<int32_t> e_rowptr, e_colind, e_blk, e_ci, e_cj, e_ct, sel_hpos;   // hierarchy on [own rows | overlap rows]
+   std::vector<double> e_val;
+   int64_t n_sel = 0;
+   bool ras = false;
+};
 
-   std::vector<int32_t> colind_ext ((size_t) nnz_loc + 1), halo_rows ((size_t) nnz_loc + 1), need (P), give (P), ones (P, 1);
-   int64_t n_halo = 0;
+static int dist_plan (DistPlan &D, const nkp_comm_ops *comm, const nkp_options &o, const std::vector<int64_t> &starts, int64_t fst_row, int64_t m_loc,
+                      int64_t nnz_loc, const int32_t *rowptr_loc, const int32_t *colind_glob, const double *val, const int32_t *blk_start_loc,
+                      int64_t nblk_loc, int coupled_tracer_cnt)
+{
+   const int P = comm->nranks, rank = comm->rank;
+   auto &colind_ext = D.colind_ext; auto &halo_rows = D.halo_rows; auto &send_rows = D.send_rows; auto &need = D.need; auto &give = D.give;
+   auto &n_halo = D.n_halo; auto &nsend = D.nsend;
+   auto &e_rowptr = D.e_rowptr; auto &e_colind = D.e_colind; auto &e_blk = D.e_blk; auto &e_ci = D.e_ci; auto &e_cj = D.e_cj; auto &e_ct = D.e_ct;
+   auto &sel_hpos = D.sel_hpos; auto &e_val = D.e_val; auto &n_sel = D.n_sel; auto &ras = D.ras;
+   n_halo = nsend = n_sel = 0;
+   ras = false;
+   colind_ext.assign ((size_t) nnz_loc + 1, 0);
+   halo_rows.assign ((size_t) nnz_loc + 1, 0);
+   need.assign (P, 0);
+   give.assign (P, 0);
+   std::vector<int32_t> ones (P, 1);
    int rc = nkp_dist_plan_host (m_loc, nnz_loc, rowptr_loc, colind_glob, rank, P, starts.data (), colind_ext.data (), halo_rows.data (), &n_halo, need.data ());
    if (rc) return rc;
    // tell every owner how many and which of its rows this rank reads
    if (comm->alltoallv_i32_host (comm->ctx, need.data (), ones.data (), give.data (), ones.data ())) return fail (NKP_ECOMM, "nkp_create_dist: count exchange failed");
-   int64_t nsend = 0;
    for (int p = 0; p < P; p++) nsend += give[p];
-   std::vector<int32_t> send_rows ((size_t) nsend + 1);
+   send_rows.assign ((size_t) nsend + 1, 0);
    if (comm->alltoallv_i32_host (comm->ctx, halo_rows.data (), need.data (), send_rows.data (), give.data ())) return fail (NKP_ECOMM, "nkp_create_dist: index exchange failed");
    for (int64_t q = 0; q < nsend; q++) {
       send_rows[q] -= (int32_t) fst_row;
       if (send_rows[q] < 0 || send_rows[q] >= m_loc) return fail (NKP_ECOMM, "nkp_create_dist: a peer asked for a row this rank does not own");
    }
-   nkp_options o;
-   if (opt) o = *opt;
-   else nkp_default_options (&o);
-   o.rank = rank;
 
    // ---- restricted additive Schwarz (overlap of one ring of water columns) -------------------------------------------
    // A hierarchy built from the rank's diagonal block alone treats the cut through the ocean as a wall: latitude bands cost
@@ -1199,10 +1201,6 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
       if (comm->allgather_i64_host (comm->ctx, want_ras, all.data ())) return fail (NKP_ECOMM, "nkp_create_dist: allgather failed");
       for (int p = 0; p < P; p++) want_ras = want_ras && all[p];
    }
-   std::vector<int32_t> e_rowptr, e_colind, e_blk, e_ci, e_cj, e_ct, sel_hpos;
-   std::vector<double> e_val;
-   int64_t n_sel = 0;
-   bool ras = false;
    if (want_ras) {
 #define XCHG(sendp, scnt, recvp, rcnt, what) do { if (comm->alltoallv_i32_host (comm->ctx, (sendp), (scnt), (recvp), (rcnt))) return fail (NKP_ECOMM, "nkp_create_dist: %s exchange failed", what); } while (0)
       std::vector<int32_t> col_of ((size_t) m_loc + 1);
@@ -1412,6 +1410,106 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
       for (int p = 0; p < P; p++) ras = ras || all[p] > 0;
    }
 
+   return NKP_OK;
+}
+
+struct nkp_dist_plan { DistPlan D; int nranks = 0; int64_t m_loc = 0, nnz_loc = 0; };
+
+extern "C" int nkp_dist_overlap_plan_host (nkp_dist_plan **out, const nkp_options *opt, int64_t n_global, int64_t fst_row, int64_t m_loc, int64_t nnz_loc,
+                                           const int32_t *rowptr_loc, const int32_t *colind_glob, const double *val, const int32_t *blk_start_loc,
+                                           int64_t nblk_loc, int coupled_tracer_cnt, const nkp_comm_ops *comm)
+{
+   if (!out || !comm || !rowptr_loc || !comm->alltoallv_i32_host || !comm->allgather_i64_host) return fail (NKP_EINVAL, "nkp_dist_overlap_plan_host: bad arguments");
+   *out = nullptr;
+   const int P = comm->nranks;
+   std::vector<int64_t> starts (P + 1, 0);
+   if (comm->allgather_i64_host (comm->ctx, fst_row, starts.data ())) return fail (NKP_ECOMM, "nkp_dist_overlap_plan_host: allgather failed");
+   starts[P] = n_global;
+   nkp_options o;
+   if (opt) o = *opt;
+   else nkp_default_options (&o);
+   nkp_dist_plan *pl = new nkp_dist_plan;
+   pl->nranks = P;
+   pl->m_loc = m_loc;
+   pl->nnz_loc = nnz_loc;
+   const int rc = dist_plan (pl->D, comm, o, starts, fst_row, m_loc, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt);
+   if (rc) { delete pl; return rc; }
+   *out = pl;
+   return NKP_OK;
+}
+
+// one table for sizes and copies: name -> (pointer, element count, element size)
+static bool dist_plan_field (const nkp_dist_plan *p, const char *what, const void **ptr, int64_t *count, size_t *elem)
+{
+   const DistPlan &D = p->D;
+   const int64_t n_ext = p->m_loc + D.n_sel;
+   struct F { const char *name; const void *ptr; int64_t count; size_t elem; };
+   const F fields[] = {
+      { "colind_ext", D.colind_ext.data (), p->nnz_loc, 4 }, { "halo_rows", D.halo_rows.data (), D.n_halo, 4 }, { "send_rows", D.send_rows.data (), D.nsend, 4 },
+      { "need", D.need.data (), p->nranks, 4 }, { "give", D.give.data (), p->nranks, 4 },
+      { "rowptr", D.e_rowptr.data (), D.e_rowptr.empty () ? 0 : n_ext + 1, 4 }, { "colind", D.e_colind.data (), (int64_t) D.e_colind.size (), 4 },
+      { "val", D.e_val.data (), (int64_t) D.e_val.size (), 8 }, { "blk_start", D.e_blk.data (), (int64_t) D.e_blk.size (), 4 },
+      { "col_i", D.e_ci.data (), (int64_t) D.e_ci.size (), 4 }, { "col_j", D.e_cj.data (), (int64_t) D.e_cj.size (), 4 }, { "col_t", D.e_ct.data (), (int64_t) D.e_ct.size (), 4 },
+      { "sel_hpos", D.sel_hpos.data (), D.n_sel, 4 },
+   };
+   for (const F &f : fields)
+      if (!strcmp (what, f.name)) { *ptr = f.ptr; *count = f.count; *elem = f.elem; return true; }
+   return false;
+}
+
+extern "C" int64_t nkp_dist_plan_size (const nkp_dist_plan *p, const char *what)
+{
+   if (!p || !what) return -1;
+   if (!strcmp (what, "ras")) return p->D.ras ? 1 : 0;
+   if (!strcmp (what, "n_sel")) return p->D.n_sel;
+   if (!strcmp (what, "n_halo")) return p->D.n_halo;
+   const void *ptr; int64_t count; size_t elem;
+   return dist_plan_field (p, what, &ptr, &count, &elem) ? count : -1;
+}
+
+extern "C" int nkp_dist_plan_copy (const nkp_dist_plan *p, const char *what, void *dst)
+{
+   const void *ptr; int64_t count; size_t elem;
+   if (!p || !what || !dst || !dist_plan_field (p, what, &ptr, &count, &elem)) return fail (NKP_EINVAL, "nkp_dist_plan_copy: unknown field");
+   if (count > 0) memcpy (dst, ptr, (size_t) count * elem);
+   return NKP_OK;
+}
+
+extern "C" void nkp_dist_plan_free (nkp_dist_plan *p) { delete p; }
+
+extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_t n_global, int64_t fst_row, int64_t m_loc,
+                                int64_t nnz_loc, const int32_t *rowptr_loc, const int32_t *colind_glob, const double *val,
+                                const int32_t *blk_start_loc, int64_t nblk_loc, int coupled_tracer_cnt, const nkp_comm_ops *comm)
+{
+   if (!out) return fail (NKP_EINVAL, "nkp_create_dist: out is NULL");
+   *out = nullptr;
+   if (!comm || (comm->nranks <= 1 && !getenv ("NKP_FORCE_DIST"))) {
+      if (fst_row != 0 || m_loc != n_global) return fail (NKP_EINVAL, "nkp_create_dist: a single rank must own all rows");
+      return create_impl (out, opt, n_global, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt, nullptr);
+   }
+   if (!comm->allreduce || !comm->alltoallv || !comm->alltoallv_i32_host || !comm->allgather_i64_host)
+      return fail (NKP_EINVAL, "nkp_create_dist: incomplete nkp_comm_ops");
+   if (!rowptr_loc || m_loc < 0 || nnz_loc < 0 || (nnz_loc > 0 && (!colind_glob || !val))) return fail (NKP_EINVAL, "nkp_create_dist: bad matrix arguments");
+   const int P = comm->nranks, rank = comm->rank;
+   std::vector<int64_t> starts (P + 1, 0);
+   if (comm->allgather_i64_host (comm->ctx, fst_row, starts.data ())) return fail (NKP_ECOMM, "nkp_create_dist: allgather failed");
+   starts[P] = n_global;
+   for (int p = 0; p < P; p++)
+      if (starts[p + 1] < starts[p] || starts[0] != 0) return fail (NKP_EINVAL, "nkp_create_dist: row blocks must be contiguous and ascending over the ranks");
+   if (starts[rank + 1] - starts[rank] != m_loc) return fail (NKP_EINVAL, "nkp_create_dist: m_loc does not match the next rank's fst_row");
+
+   nkp_options o;
+   if (opt) o = *opt;
+   else nkp_default_options (&o);
+   o.rank = rank;
+   DistPlan D;
+   int rc = dist_plan (D, comm, o, starts, fst_row, m_loc, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt);
+   if (rc) return rc;
+   auto &colind_ext = D.colind_ext; auto &send_rows = D.send_rows; auto &need = D.need; auto &give = D.give;
+   const int64_t n_halo = D.n_halo, nsend = D.nsend, n_sel = D.n_sel;
+   auto &e_rowptr = D.e_rowptr; auto &e_colind = D.e_colind; auto &e_blk = D.e_blk; auto &e_ci = D.e_ci; auto &e_cj = D.e_cj; auto &e_ct = D.e_ct;
+   auto &sel_hpos = D.sel_hpos; auto &e_val = D.e_val;
+   const bool ras = D.ras;
    // diagonal block: what the create path validates and what the hierarchy is built from without overlap
    std::vector<int32_t> drow ((size_t) m_loc + 1, 0), dcol;
    std::vector<double> dval;

@@ -105,6 +105,40 @@ def plan_host(rowptr_loc, colind_glob, starts, rank):
     return ext[:ci.size], halo[:nh.value].copy(), need
 
 
+def overlap_plan_host(loc, n_global, comm, coupled_tracer_cnt=1):
+    """nkp_dist_overlap_plan_host: everything nkp_create_dist decides on the host (halo of the SpMV, overlap of the
+    hierarchy), as a dict of numpy arrays.  Collective; needs no GPU (the callbacks used are the host ones)."""
+    lib = _solver.load_library()
+    opt = _solver.default_options()
+    rp, ci, v, bs = loc["rowptr"], loc["colind"], loc["val"], loc["blk_start"]
+    keep = [np.ascontiguousarray(loc[k], np.int32) for k in ("col_i", "col_j", "col_t") if loc.get(k) is not None]
+    if loc.get("col_i") is not None:
+        opt.col_i, opt.col_j = _solver._p(keep[0], C.c_int32), _solver._p(keep[1], C.c_int32)
+    if loc.get("col_t") is not None:
+        opt.col_t = _solver._p(keep[-1], C.c_int32)
+    h = C.c_void_p()
+    lib.nkp_dist_overlap_plan_host.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int64, C.c_int, C.c_void_p]
+    lib.nkp_dist_plan_size.restype = C.c_int64
+    lib.nkp_dist_plan_size.argtypes = [C.c_void_p, C.c_char_p]
+    lib.nkp_dist_plan_copy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+    lib.nkp_dist_plan_free.argtypes = [C.c_void_p]
+    rc = lib.nkp_dist_overlap_plan_host(C.byref(h), C.cast(C.byref(opt), C.c_void_p), int(n_global), int(loc["fst_row"]), int(loc["m_loc"]), int(ci.size),
+                                        _solver._p(rp, C.c_int32), _solver._p(ci, C.c_int32), _solver._p(v, C.c_double), _solver._p(bs, C.c_int32),
+                                        int(bs.size - 1), int(coupled_tracer_cnt), C.cast(C.byref(comm.ops), C.c_void_p))
+    if rc != 0:
+        raise _solver.NkpError(rc, lib.nkp_last_error().decode() + (" | comm: " + "; ".join(comm.errors) if comm.errors else ""))
+    out = dict(ras=int(lib.nkp_dist_plan_size(h, b"ras")))
+    for name in ("colind_ext", "halo_rows", "send_rows", "need", "give", "rowptr", "colind", "val", "blk_start", "col_i", "col_j", "col_t", "sel_hpos"):
+        cnt = int(lib.nkp_dist_plan_size(h, name.encode()))
+        arr = np.empty(max(cnt, 0), np.float64 if name == "val" else np.int32)
+        if cnt > 0:
+            lib.nkp_dist_plan_copy(h, name.encode(), arr.ctypes.data_as(C.c_void_p))
+        out[name] = arr
+    lib.nkp_dist_plan_free(h)
+    return out
+
+
 class _DevArray:
     def __init__(self, ptr, n, typestr):
         self.__cuda_array_interface__ = dict(shape=(int(n),), typestr=typestr, data=(int(ptr), False), version=3)

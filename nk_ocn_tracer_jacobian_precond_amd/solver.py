@@ -27,7 +27,8 @@ ABI_SYMBOLS = [
     "nkp_get_int", "nkp_set_stream", "nkp_destroy", "nkp_last_error", "nkp_comm_unique_id",
     "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host", "nkp_set_device",
     "nkp_gather_root", "nkp_clone", "nkp_ml_plan_host", "nkp_comm_file_init", "nkp_comm_file_free",
-    "nkp_create64", "nkp_cell_major_order", "nkp_permuted_rows",
+    "nkp_create64", "nkp_cell_major_order", "nkp_permuted_rows", "nkp_dist_overlap_plan_host", "nkp_dist_plan_size",
+    "nkp_dist_plan_copy", "nkp_dist_plan_free",
 ]
 
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)

@@ -38,9 +38,13 @@ def main():
     n = p.flat_len
     blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
     ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    gblk, gci, gcj, gct = blk, ci, cj, np.zeros(len(blk) - 1, np.int64)        # global column table (checks only)
     if a.partition == "tracers":
         loc, starts, n = nd.tracer_slice(p, rank, world)
         p = synth.generate(imt=imt, jmt=jmt, km=km, adv="upwind3", hmix="isop", seed=a.seed, coupled_tracer_cnt=world)   # global matrix: checks only
+        gblk = solver.column_blocks(p.col_start(), p.tracer_state_len, world)
+        gci, gcj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), world)
+        gct = np.arange(len(gblk) - 1) // ((len(gblk) - 1) // world)
     elif a.partition == "cells":
         import types
         cnt = 2
@@ -52,6 +56,8 @@ def main():
         A2 = p2.scipy_csr()[perm][:, perm].tocsr()          # the global matrix in the new numbering: checks only
         A2.sort_indices()
         p = types.SimpleNamespace(rowptr=A2.indptr.astype(np.int32), colind=A2.indices.astype(np.int32), nzval=A2.data)
+        _, _, gblk, gct, src = solver.cell_major_order(blk2, cnt)
+        gci, gcj = np.asarray(ci2)[src], np.asarray(cj2)[src]
     else:
         starts = nd.snap_partition(blk, world)
         loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, starts, rank, ci, cj)
@@ -80,6 +86,45 @@ def main():
         result["spmv_bit_exact"] = bool(np.array_equal(y_loc, y_ref))
         result["n_halo"] = int(halo.size)
         result["neighbours"] = int((need > 0).sum())
+    elif a.mode == "cpu-overlap-plan":
+        # nkp_create_dist's whole host-side plan (no GPU): completed halo, overlap selection, the matrix of the hierarchy
+        import scipy.sparse as sp
+        cnt_loc = 2 if a.partition == "cells" else 1
+        pl = nd.overlap_plan_host(loc, n, comm, cnt_loc)
+        A = sp.csr_matrix((p.nzval, p.colind, p.rowptr), shape=(n, n))
+        gblk = np.asarray(gblk, np.int64)
+        col_of = np.repeat(np.arange(gblk.size - 1), np.diff(gblk))
+        own = np.arange(f, f + m)
+        ref = np.unique(A[own].indices)
+        ref = ref[(ref < f) | (ref >= f + m)]
+        hcols = np.unique(col_of[ref])
+        want_halo = np.concatenate([np.arange(gblk[c], gblk[c + 1]) for c in hcols]) if hcols.size else np.zeros(0, np.int64)
+        result["halo_complete"] = bool(np.array_equal(pl["halo_rows"], want_halo))
+        x_ext = np.concatenate([xg[own], xg[pl["halo_rows"]]])
+        y_loc = ora.spmv(loc["rowptr"], pl["colind_ext"], loc["val"], x_ext)
+        result["spmv_bit_exact"] = bool(np.array_equal(y_loc, ora.spmv(p.rowptr, p.colind, p.nzval, xg)[own]))
+        # lateral neighbours: halo columns at a position no own column has
+        own_cols = np.unique(col_of[own])
+        own_pos = set(zip(np.asarray(gci)[own_cols].tolist(), np.asarray(gcj)[own_cols].tolist()))
+        sel_cols = np.array([c for c in hcols if (int(gci[c]), int(gcj[c])) not in own_pos], np.int64)
+        sel_rows = np.concatenate([np.arange(gblk[c], gblk[c + 1]) for c in sel_cols]) if sel_cols.size else np.zeros(0, np.int64)
+        parts = [None] * world
+        dist.all_gather_object(parts, int(sel_rows.size))
+        result["ras"], result["ras_expected"] = pl["ras"], int(any(q > 0 for q in parts))
+        result["n_sel"] = int(pl["sel_hpos"].size)
+        if pl["ras"]:
+            ext = np.concatenate([own, sel_rows])
+            want = A[ext][:, ext].tocsr()
+            want.sort_indices()
+            result["sel_rows_ok"] = bool(np.array_equal(pl["halo_rows"][pl["sel_hpos"]], sel_rows))
+            result["ext_matrix_ok"] = bool(np.array_equal(pl["rowptr"], want.indptr) and np.array_equal(pl["colind"], want.indices)
+                                           and np.array_equal(pl["val"], want.data))
+            lens = np.concatenate([np.diff(gblk)[own_cols], np.diff(gblk)[sel_cols]])
+            result["blocks_ok"] = bool(np.array_equal(pl["blk_start"], np.concatenate([[0], np.cumsum(lens)])))
+            cols = np.concatenate([own_cols, sel_cols])
+            result["coords_ok"] = bool(np.array_equal(pl["col_i"], np.asarray(gci)[cols]) and np.array_equal(pl["col_j"], np.asarray(gcj)[cols]))
+            t = np.asarray(gct)[cols]
+            result["tracers_ok"] = bool(np.array_equal(pl["col_t"], t - t.min()))
     else:
         torch.cuda.set_device(0)
         b = rng.standard_normal(n)

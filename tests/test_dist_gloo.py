@@ -176,3 +176,19 @@ def test_cell_major_order_and_slices():
         loc = nd.local_slice(p.rowptr, p.colind, p.nzval, blk, st, r)
         tracer_major_halo += nd.plan_host(loc["rowptr"], loc["colind"], st, r)[1].size
     assert halo_total < 0.5 * tracer_major_halo, (halo_total, tracer_major_halo)
+
+
+@pytest.mark.parametrize("world,partition", [(2, "bands"), (3, "bands"), (2, "cells"), (3, "cells"), (2, "tracers")])
+def test_overlap_plan_over_gloo(tmp_path, world, partition):
+    """Everything nkp_create_dist decides on the host, on CPU over gloo (nkp_dist_overlap_plan_host): the halo completed to
+    whole water columns keeps the distributed SpMV bit-exact; the overlap picks exactly the lateral neighbours (every halo
+    column of a band cut, none of the other tracers' columns of a tracer cut); and the matrix the rank's hierarchy is built
+    from is the global matrix restricted to [own rows | overlap rows], entry for entry."""
+    res = launch(world, "cpu-overlap-plan", str(tmp_path / "oplan"), extra=("--partition", partition))
+    assert all(r["halo_complete"] and r["spmv_bit_exact"] for r in res), res
+    assert all(r["ras"] == r["ras_expected"] for r in res), res
+    if partition == "tracers":
+        assert all(r["ras"] == 0 and r["n_sel"] == 0 for r in res), res
+    else:
+        assert all(r["ras"] == 1 for r in res) and sum(r["n_sel"] for r in res) > 0, res
+        assert all(r["sel_rows_ok"] and r["ext_matrix_ok"] and r["blocks_ok"] and r["coords_ok"] and r["tracers_ok"] for r in res), res
