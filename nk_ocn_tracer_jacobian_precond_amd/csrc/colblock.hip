@@ -636,6 +636,135 @@ void colblock_apply_stream_kernel (const int *__restrict__ grp_nb, const int *__
       for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
 }
 
+
+// ================================================================ lane-per-column apply, 32 columns per wave, column resident in LDS
+// The streamed kernel above keeps the whole column in registers (2 VGPRs per level): at 80 levels nothing is left for
+// loads in flight and it loses to the small-group kernel, which in turn runs at a fifth of the HBM peak there.  Here the
+// column stays in LDS, where the right-hand side is staged anyway: a substitution step reads its right-hand side from LDS
+// and writes its result back, the registers hold only the P previous values and TWO chunks of CH steps' factors -- the
+// chunk being consumed and the next one, requested before the current one is used -- so the register count does not
+// depend on the column length.  Same operations in the same order as the other kernels => same bits.
+template <int P, int CH, class FT>
+struct FacChunk { FT f[P + 1][CH]; };
+
+template <int P, int CH, class FT>
+__device__ __forceinline__ void load_fwd (FacChunk<P, CH, FT> &c, const FT *__restrict__ ft, int dstride, int k0, int gw)
+{
+#pragma unroll
+   for (int q = 1; q <= P; q++)
+#pragma unroll
+      for (int j = 0; j < CH; j++) c.f[q - 1][j] = ft[(P - q) * dstride + (k0 + j) * gw];
+}
+
+template <int P, int CH, class FT>
+__device__ __forceinline__ void load_bwd (FacChunk<P, CH, FT> &c, const FT *__restrict__ ft, int dstride, int k0, int gw)
+{
+#pragma unroll
+   for (int q = 0; q <= P; q++)
+#pragma unroll
+      for (int j = 0; j < CH; j++) c.f[q][j] = ft[(P + q) * dstride + (k0 + j) * gw];
+}
+
+// steps k0 .. k0 + CH - 1 of the forward substitution; w[q - 1] = y_{k - q} on entry and on exit
+template <int P, int CH, class FT>
+__device__ __forceinline__ void step_fwd (const FacChunk<P, CH, FT> &c, double *lds, int s, int len, int k0, double (&w)[P])
+{
+   double b[CH];
+#pragma unroll
+   for (int j = 0; j < CH; j++) b[j] = (k0 + j < len) ? lds[LDS_PAD (s + k0 + j)] : 0.0;
+#pragma unroll
+   for (int j = 0; j < CH; j++) {
+      double y = b[j];
+#pragma unroll
+      for (int q = P; q >= 1; q--)
+         if (k0 + j - q >= 0) y -= (double) c.f[q - 1][j] * w[q - 1];
+#pragma unroll
+      for (int q = P - 1; q >= 1; q--) w[q] = w[q - 1];
+      w[0] = y;
+      if (k0 + j < len) lds[LDS_PAD (s + k0 + j)] = y;
+   }
+}
+
+// steps k0 + CH - 1 .. k0 of the back substitution; u[q - 1] = x_{k + q}
+template <int P, int CH, class FT>
+__device__ __forceinline__ void step_bwd (const FacChunk<P, CH, FT> &c, double *lds, int s, int len, int k0, double (&u)[P])
+{
+   double y[CH];
+#pragma unroll
+   for (int j = 0; j < CH; j++) y[j] = (k0 + j < len) ? lds[LDS_PAD (s + k0 + j)] : 0.0;
+#pragma unroll
+   for (int j = CH - 1; j >= 0; j--) {
+      double x = y[j];
+#pragma unroll
+      for (int q = P; q >= 1; q--) x -= (double) c.f[q][j] * u[q - 1];
+      x *= (double) c.f[0][j];
+#pragma unroll
+      for (int q = P - 1; q >= 1; q--) u[q] = u[q - 1];
+      u[0] = x;
+      if (k0 + j < len) lds[LDS_PAD (s + k0 + j)] = x;
+   }
+}
+
+template <int P, class FT, int CH>
+__global__ __launch_bounds__ (NKP_WAVE)
+void colblock_apply_ldsres_kernel (const int *__restrict__ grp_nb, const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
+                                   const FT *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
+                                   const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp)
+{
+   extern __shared__ double lds[];            // the group's right-hand side, then its solution
+   constexpr int gw = 32;
+   const int g = blockIdx.x + g_first;
+   const int lane = threadIdx.x;
+   const int nb = grp_nb[g], ml = grp_maxlen[g];            // ml is a multiple of CH (layout built for this kernel)
+   const int R0 = grp_row0[g], nrows = grp_row0[ngrp + g];
+   int s = 0, len = 0;
+   if (lane < gw) { s = col_slot[g * gw + lane]; len = col_slot[(ngrp + g) * gw + lane]; }
+   const FT *ft = fac_t + grp_base[g] + lane;
+   const int dstride = ml * gw;
+   for (int i0 = lane; i0 < nrows; i0 += 8 * NKP_WAVE) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = (i0 + u * NKP_WAVE < nrows) ? rhs[(int64_t) R0 + i0 + u * NKP_WAVE] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+         if (i0 + u * NKP_WAVE < nrows) lds[LDS_PAD (i0 + u * NKP_WAVE)] = t[u];
+   }
+   __syncthreads ();
+   if (lane < nb) {
+      FacChunk<P, CH, FT> A, B;
+      double w[P];
+#pragma unroll
+      for (int q = 0; q < P; q++) w[q] = 0.0;
+      load_fwd<P, CH, FT> (A, ft, dstride, 0, gw);
+      for (int k0 = 0; k0 < ml; k0 += 2 * CH) {
+         const bool more = k0 + CH < ml;
+         if (more) load_fwd<P, CH, FT> (B, ft, dstride, k0 + CH, gw);
+         step_fwd<P, CH, FT> (A, lds, s, len, k0, w);
+         if (more) {
+            if (k0 + 2 * CH < ml) load_fwd<P, CH, FT> (A, ft, dstride, k0 + 2 * CH, gw);
+            step_fwd<P, CH, FT> (B, lds, s, len, k0 + CH, w);
+         }
+      }
+#pragma unroll
+      for (int q = 0; q < P; q++) w[q] = 0.0;
+      load_bwd<P, CH, FT> (A, ft, dstride, ml - CH, gw);
+      for (int k0 = ml - CH; k0 >= 0; k0 -= 2 * CH) {
+         const bool more = k0 - CH >= 0;
+         if (more) load_bwd<P, CH, FT> (B, ft, dstride, k0 - CH, gw);
+         step_bwd<P, CH, FT> (A, lds, s, len, k0, w);
+         if (more) {
+            if (k0 - 2 * CH >= 0) load_bwd<P, CH, FT> (A, ft, dstride, k0 - 2 * CH, gw);
+            step_bwd<P, CH, FT> (B, lds, s, len, k0 - CH, w);
+         }
+      }
+   }
+   __syncthreads ();
+   if (accumulate)
+      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] += lds[LDS_PAD (i)];
+   else
+      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
+}
+
 template <class T>
 static int up (T **dst, const std::vector<T> &src, size_t *bytes)
 {
@@ -677,8 +806,14 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       // 0.25 degree x 80 levels: cycle 46.2 ms with it against 32.8 ms with the small-group kernel
       B.stream = on && ranges[nranges] - ranges[0] >= min_cols && B.max_len <= 64;
       if (B.stream) gw = sgw;
+      // longer columns: the column stays in LDS (colblock_apply_ldsres_kernel); NKP_COL_LDSRES=0 disables, =2 also takes the
+      // levels the streamed kernel would take
+      int lr = 1;
+      if (const char *e = getenv ("NKP_COL_LDSRES")) lr = atoi (e);
+      B.ldsres = lr > 0 && on && ranges[nranges] - ranges[0] >= min_cols && B.max_len <= 128 && (B.max_len > 64 || lr == 2);
+      if (B.ldsres) { B.stream = 0; gw = 32; }
    }
-   while (!B.stream && gw > 8 && (size_t) ((2 * B.P + 2) * ((B.max_len + 7) & ~7) * gw) * sizeof (double) > 56 * 1024) gw >>= 1;
+   while (!B.stream && !B.ldsres && gw > 8 && (size_t) ((2 * B.P + 2) * ((B.max_len + 7) & ~7) * gw) * sizeof (double) > 56 * 1024) gw >>= 1;
    B.gw = gw;
    long long total = 0;
    int lds_need = 0, fac_need = 0;
@@ -689,7 +824,7 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
          const int cnt = std::min (gw, ranges[r + 1] - b);
          int m = 0;
          for (int c = b; c < b + cnt; c++) m = std::max (m, h_blk_start[c + 1] - h_blk_start[c]);
-         m = (m + 7) & ~7;                          // the apply kernel steps in chunks of 8 (zero-padded factors)
+         m = B.ldsres ? (m + NKP_LDSRES_CH - 1) / NKP_LDSRES_CH * NKP_LDSRES_CH : (m + 7) & ~7;   // the apply kernels step in chunks (zero-padded factors)
          const int rows = h_blk_start[b + cnt] - h_blk_start[b];
          lds_need = std::max (lds_need, LDS_PAD (rows) + 2);
          fac_need = std::max (fac_need, ndiag * m * gw);
@@ -729,7 +864,7 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    B.ngrp = (int) b0.size ();
    lds_need = (lds_need + 1) & ~1;                 // keep the factor area 16-byte aligned
    B.rhs_slots = lds_need;
-   if (!B.stream) lds_need += f32 ? (fac_need + 1) / 2 : fac_need;      // doubles
+   if (!B.stream && !B.ldsres) lds_need += f32 ? (fac_need + 1) / 2 : fac_need;      // doubles
    B.lds_doubles = lds_need;
    int rc;
    if ((rc = up (&B.grp_b0, b0, device_bytes)) || (rc = up (&B.grp_nb, nb, device_bytes)) || (rc = up (&B.grp_maxlen, ml, device_bytes)) ||
@@ -774,6 +909,11 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       (void) hipFuncSetAttribute ((const void *) colblock_apply_stream_kernel<PP, ML, double, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
       (void) hipFuncSetAttribute ((const void *) colblock_apply_stream_kernel<PP, ML, float, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
       LDS_OPT_IN (1, 64); LDS_OPT_IN (2, 64); LDS_OPT_IN (4, 64); LDS_OPT_IN (1, 96); LDS_OPT_IN (2, 96); LDS_OPT_IN (4, 96);
+#undef LDS_OPT_IN
+#define LDS_OPT_IN(PP)                                                                                                                    \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_ldsres_kernel<PP, double, NKP_LDSRES_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_ldsres_kernel<PP, float, NKP_LDSRES_CH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
+      LDS_OPT_IN (1); LDS_OPT_IN (2); LDS_OPT_IN (4);
 #undef LDS_OPT_IN
    }
    return (int) hipStreamSynchronize (st);
@@ -1095,6 +1235,20 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
                                   B.fac_tf, r, z, accumulate, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp);
          return;
       }
+   }
+   if (B.ldsres) {
+#define LDSRES_LAUNCH(PP)                                                                                                                                         \
+      do {                                                                                                                                                       \
+         if (B.fac_tf) hipLaunchKernelGGL ((colblock_apply_ldsres_kernel<PP, float, NKP_LDSRES_CH>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.grp_nb, B.grp_maxlen, \
+                                           B.grp_base, g0, B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp);                                           \
+         else hipLaunchKernelGGL ((colblock_apply_ldsres_kernel<PP, double, NKP_LDSRES_CH>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.grp_nb, B.grp_maxlen,         \
+                                  B.grp_base, g0, B.fac_t, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp);                                                    \
+      } while (0)
+      if (B.P == 1) LDSRES_LAUNCH (1);
+      else if (B.P == 2) LDSRES_LAUNCH (2);
+      else LDSRES_LAUNCH (4);
+#undef LDSRES_LAUNCH
+      return;
    }
    if (B.stream) {
 #define STREAM_LAUNCH3(PP, ML, GG)                                                                                                                              \

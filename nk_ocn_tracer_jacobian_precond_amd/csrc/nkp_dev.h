@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define NKP_LDSRES_CH 16         // substitution steps per factor chunk of colblock_apply_ldsres_kernel (group lengths are padded to it)
 #define NKP_WAVE 64
 #define NKP_MAX_K 512           // most basis vectors a fused update kernel takes (LDS coefficients)
 
@@ -71,6 +72,7 @@ struct ColBlocksDev {
    int rhs_slots = 0;          // LDS doubles reserved for the staged right-hand side
    // fused Gauss-Seidel half sweep (gs_fused_kernel): row blocks of every group's rows
    int stream = 0;             // 1: 64 columns per wave, factors read straight from HBM (colblock_apply_stream_kernel)
+   int ldsres = 0;             // 1: 32 columns per wave, factors streamed, the column resident in LDS (colblock_apply_ldsres_kernel)
    int gs_ok = 0;              // 1 if the level can run it (no row longer than GS_NNZ, LDS need within 64 KB)
    int gs_lds_bytes = 0;
    int *gs_rb_ptr = nullptr;   // [ngrp+1] first row-block boundary of the group

@@ -675,6 +675,37 @@ def test_column_stream_kernel_is_bit_identical(case, medium, monkeypatch):
         assert np.array_equal(z["0"], z["1"]), (case, precond, np.abs(z["0"] - z["1"]).max())
 
 
+@pytest.mark.parametrize("case", ["medium", "long_columns", "wide_band"])
+def test_column_lds_resident_kernel_is_bit_identical(case, medium, monkeypatch):
+    """colblock_apply_ldsres_kernel (32 water columns per wave, factors streamed in double-buffered chunks of 16 steps, the
+    column itself resident in LDS so that the register count does not grow with the column length -- the kernel for columns
+    of more than 64 levels) against the 8-columns-per-wave kernel: same substitutions in the same order => same bits, with
+    f32 and f64 factor storage, as a preconditioner of its own and on every level of the multilevel cycle."""
+    if case == "medium":
+        p, blk = medium
+    elif case == "long_columns":
+        p = synth.generate(imt=24, jmt=20, km=70, adv="centred", hmix="const", seed=5)
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    else:
+        p = synth.generate(imt=30, jmt=24, km=20, adv="upwind3", hmix="isop", seed=6)       # upwind3: in-column band of 2
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    r = np.random.default_rng(39).standard_normal(p.flat_len)
+    monkeypatch.setenv("NKP_COLSTREAM_MIN", "1")
+    monkeypatch.setenv("NKP_COLWAVE_MAX", "0")              # no wave-per-column kernel on the small levels: every level takes the kernel under test
+    for f32 in ("1", "0"):
+        monkeypatch.setenv("NKP_ML_F32", f32)
+        for precond, kw in ((solver.PRECOND_COLUMN_JACOBI, {}), (solver.PRECOND_MULTILEVEL, dict(col_i=ci, col_j=cj))):
+            z = {}
+            for variant, (stream, ldsres) in (("lanes", ("0", "0")), ("ldsres", ("1", "2"))):
+                monkeypatch.setenv("NKP_COLSTREAM", stream)
+                monkeypatch.setenv("NKP_COL_LDSRES", ldsres)
+                with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, precond=precond, restart=4, **kw) as s:
+                    z[variant] = s.precond_apply(r)
+            assert np.isfinite(z["ldsres"]).all()
+            assert np.array_equal(z["lanes"], z["ldsres"]), (case, f32, precond, np.abs(z["lanes"] - z["ldsres"]).max())
+
+
 @pytest.mark.parametrize("case", ["medium", "long_columns", "tracers2"])
 def test_wave_per_column_on_small_levels_is_bit_identical(case, medium, monkeypatch):
     """Levels with few columns solve them one per WAVE (colblock_apply_kernel, factors rounded to f32 on load in the f32
