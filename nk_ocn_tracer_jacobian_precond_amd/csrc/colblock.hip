@@ -810,7 +810,10 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       // levels the streamed kernel would take
       int lr = 1;
       if (const char *e = getenv ("NKP_COL_LDSRES")) lr = atoi (e);
-      B.ldsres = lr > 0 && on && ranges[nranges] - ranges[0] >= min_cols && B.max_len <= 128 && (B.max_len > 64 || lr == 2);
+      // long columns have no good alternative (the capped small-group kernel runs at half the rate), so they switch earlier:
+      // 720x360x80, levels of 37 000 and 9 000 columns included: cycle 5.63 -> 5.53 ms
+      const int min_long = getenv ("NKP_COLSTREAM_MIN") ? min_cols : 8000;
+      B.ldsres = lr > 0 && on && B.max_len <= 128 && ((B.max_len > 64 && ranges[nranges] - ranges[0] >= min_long) || (lr == 2 && ranges[nranges] - ranges[0] >= min_cols));
       if (B.ldsres) { B.stream = 0; gw = 32; }
    }
    while (!B.stream && !B.ldsres && gw > 8 && (size_t) ((2 * B.P + 2) * ((B.max_len + 7) & ~7) * gw) * sizeof (double) > 56 * 1024) gw >>= 1;
