@@ -25,7 +25,7 @@ import ml_reference as mlr                                                   # n
 from nk_ocn_tracer_jacobian_precond_amd import synth                        # noqa: E402
 
 
-def band_cycle(bands, r, glob=None, nu=3, omega=1.1):
+def band_cycle(bands, r, glob=None, nu=3, omega=1.1, refresh=0):
     """One V-cycle per band; with `glob` = (inverse of the global coarsest operator, offsets) the coarsest solves of all
     bands are one solve."""
     z = np.zeros_like(r)
@@ -48,6 +48,30 @@ def band_cycle(bands, r, glob=None, nu=3, omega=1.1):
         inv, off = glob
         full = inv @ np.concatenate([st[2] for st in state])
         xc = [full[off[k]:off[k + 1]] for k in range(len(bands))]
+    if refresh:
+        # variant: before (1) or before and between (2) the post-smoothing sweeps of the FINE level the overlap rows take
+        # their owners' current values (one halo exchange of x each time)
+        fine = []
+        for bd, st, x in zip(bands, state, xc):
+            lv_list = bd["levels"]
+            xs, bs, _ = st
+            for l in range(len(lv_list) - 2, 0, -1):
+                lv = lv_list[l]
+                x = xs[l] + omega * (lv.P @ x)
+                for _ in range(nu):
+                    x = mlr._sweep(lv, x, bs[l], True)
+            lv = lv_list[0]
+            fine.append(xs[0] + omega * (lv.P @ x))
+        for sweep in range(nu):
+            if sweep == 0 or refresh == 2:
+                g = np.zeros_like(r)
+                for bd, x in zip(bands, fine):
+                    g[bd["rows"][bd["own"]]] = x[bd["own"]]
+                fine = [g[bd["rows"]] for bd in bands]
+            fine = [mlr._sweep(bd["levels"][0], x, st[1][0], True) for bd, st, x in zip(bands, state, fine)]
+        for bd, x in zip(bands, fine):
+            z[bd["rows"][bd["own"]]] = x[bd["own"]]
+        return z
     for bd, st, x in zip(bands, state, xc):
         lv_list = bd["levels"]
         xs, bs, _ = st
@@ -108,6 +132,7 @@ def main():
     ap.add_argument("--coarsest-rows", type=int, default=3000)
     ap.add_argument("--refine", type=float, default=1.0)
     ap.add_argument("--maxit", type=int, default=600)
+    ap.add_argument("--refresh", type=int, default=0, help="overlap rows take their owners' values before (1) / before and between (2) the fine level's post-smoothing sweeps")
     ap.add_argument("--overlap", type=int, default=0, help="rings of neighbouring water columns added to every band (restricted additive Schwarz)")
     a = ap.parse_args()
     imt, jmt, km = (int(t) for t in a.grid.split("x"))
@@ -169,7 +194,7 @@ def main():
             if glob is not None and (nb == 1 or a.overlap > 0):
                 continue
             t0 = time.perf_counter()
-            x, its, rr = fgmres(A, b, lambda r: band_cycle(bands, r, glob), maxit=a.maxit)
+            x, its, rr = fgmres(A, b, lambda r: band_cycle(bands, r, glob, refresh=a.refresh if a.overlap > 0 else 0), maxit=a.maxit)
             print(f"  {label:28s}: {its:4d} iterations, relres {rr:.2e}, {time.perf_counter() - t0:.0f} s", flush=True)
 
 
