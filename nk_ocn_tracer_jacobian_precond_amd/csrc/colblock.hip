@@ -806,14 +806,17 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       // 0.25 degree x 80 levels: cycle 46.2 ms with it against 32.8 ms with the small-group kernel
       B.stream = on && ranges[nranges] - ranges[0] >= min_cols && B.max_len <= 64;
       if (B.stream) gw = sgw;
-      // longer columns: the column stays in LDS (colblock_apply_ldsres_kernel); NKP_COL_LDSRES=0 disables, =2 also takes the
-      // levels the streamed kernel would take
-      int lr = 1;
+      // the column resident in LDS (colblock_apply_ldsres_kernel): the default from 20 000 columns (8000 when the columns
+      // are longer than 64 levels, where the alternative runs at half the rate).  Same box, 1 degree, cycle time twice each:
+      // LDS-resident on levels 0 and 1: 2.385 / 2.394 ms; streamed on level 0, small groups on level 1: 2.410 / 2.427;
+      // streamed on level 0, LDS-resident on level 1: 2.434 / 2.409.  NKP_COL_LDSRES=1 keeps it to the long columns (and
+      // the streamed kernel on the largest levels), =0 switches it off.
+      int lr = 2;
       if (const char *e = getenv ("NKP_COL_LDSRES")) lr = atoi (e);
-      // long columns have no good alternative (the capped small-group kernel runs at half the rate), so they switch earlier:
-      // 720x360x80, levels of 37 000 and 9 000 columns included: cycle 5.63 -> 5.53 ms
-      const int min_long = getenv ("NKP_COLSTREAM_MIN") ? min_cols : 8000;
-      B.ldsres = lr > 0 && on && B.max_len <= 128 && ((B.max_len > 64 && ranges[nranges] - ranges[0] >= min_long) || (lr == 2 && ranges[nranges] - ranges[0] >= min_cols));
+      const int ncols = ranges[nranges] - ranges[0];
+      const bool env_min = getenv ("NKP_COLSTREAM_MIN") != nullptr;
+      const int min_long = env_min ? min_cols : 8000, min_short = env_min ? min_cols : 20000;
+      B.ldsres = lr > 0 && on && B.max_len <= 128 && ((B.max_len > 64 && ncols >= min_long) || (lr == 2 && ncols >= min_short));
       if (B.ldsres) { B.stream = 0; gw = 32; }
    }
    while (!B.stream && !B.ldsres && gw > 8 && (size_t) ((2 * B.P + 2) * ((B.max_len + 7) & ~7) * gw) * sizeof (double) > 56 * 1024) gw >>= 1;

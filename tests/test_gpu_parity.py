@@ -669,6 +669,7 @@ def test_column_stream_kernel_is_bit_identical(case, medium, monkeypatch):
         for stream in ("0", "1"):
             monkeypatch.setenv("NKP_COLSTREAM", stream)
             monkeypatch.setenv("NKP_COLSTREAM_MIN", "1")
+            monkeypatch.setenv("NKP_COL_LDSRES", "0")          # the LDS-resident kernel (the default since) has its own test below
             with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, precond=precond, restart=4, **kw) as s:
                 z[stream] = s.precond_apply(r)
         assert np.isfinite(z["1"]).all()
