@@ -1180,7 +1180,10 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
       for (int s = 1; s < sweeps; s++) gs_sweep (H, V, s & 1, false, st);
       return;
    }
-   const bool fused = H.fused && V.B.gs_ok;
+   // NKP_ML_FUSED_MAX_COLS: the fused half sweep only on levels with at most that many columns (the launch-bound end)
+   static int fused_max = -1;
+   if (fused_max < 0) { const char *e = getenv ("NKP_ML_FUSED_MAX_COLS"); fused_max = e ? atoi (e) : 0; }
+   const bool fused = H.fused && V.B.gs_ok && (fused_max <= 0 || V.color_grp[2] * V.B.gw <= fused_max);
    // pre-smoothing from x = 0: the first half-sweep needs no SpMV (r = b on colour 0)
    launch_fill (V.x, 0.0, V.n, st);
    if (fused) {
