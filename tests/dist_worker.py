@@ -86,6 +86,33 @@ def main():
         result["spmv_bit_exact"] = bool(np.array_equal(y_loc, y_ref))
         result["n_halo"] = int(halo.size)
         result["neighbours"] = int((need > 0).sum())
+    elif a.mode == "gpu-selftest":
+        # the transport pre-flight must pass on a sound transport and must catch one that lies or never returns
+        import ctypes as C
+        import time
+        torch.cuda.set_device(0)
+        result["sound"] = bool(nd.comm_self_test(comm, timeout=60.0))
+        import types
+
+        def broken(fn):                                   # a copy of the transport with one callback replaced; the original stays intact
+            ops = solver.NkpCommOps()
+            C.memmove(C.byref(ops), C.byref(comm.ops), C.sizeof(ops))
+            ops.allreduce = fn
+            return types.SimpleNamespace(ops=ops)
+        lazy = solver._ALLREDUCE_FN(lambda ctx, buf, count, op, stream: 0)            # claims success, reduces nothing
+        try:
+            nd.comm_self_test(broken(lazy), timeout=60.0)
+            result["lying"] = "passed"
+        except RuntimeError as exc:
+            result["lying"] = "caught: " + str(exc)[:60]
+        slow = solver._ALLREDUCE_FN(lambda ctx, buf, count, op, stream: (time.sleep(6.0), 0)[1])
+        try:
+            nd.comm_self_test(broken(slow), timeout=1.0)
+            result["hanging"] = "passed"
+        except TimeoutError as exc:
+            result["hanging"] = "caught: " + str(exc)[:60]
+        time.sleep(7.0)                                   # let the abandoned helper thread finish before the group goes away
+        result["sound_again"] = bool(nd.comm_self_test(comm, timeout=60.0))
     elif a.mode == "cpu-overlap-plan":
         # nkp_create_dist's whole host-side plan (no GPU): completed halo, overlap selection, the matrix of the hierarchy
         import scipy.sparse as sp

@@ -186,3 +186,12 @@ def test_cell_major_order_on_one_gpu():
     assert i0["status"] == 0 and i1["status"] == 0
     assert np.linalg.norm(x1[inv] - x0) <= 1e-8 * np.linalg.norm(x0)
     assert abs(i1["iters"] - i0["iters"]) <= max(3, 0.2 * i0["iters"]), (i0["iters"], i1["iters"])
+
+
+def test_transport_self_test_catches_a_bad_transport(tmp_path):
+    """dist.comm_self_test, the pre-flight bench.py runs before it builds on the library's RCCL communicator: passes on a
+    sound transport, raises on one whose allreduce returns without reducing, and reports (instead of hanging with it) one
+    whose call does not come back within the deadline."""
+    res = launch(2, "gpu-selftest", str(tmp_path / "selftest"))
+    assert all(r["sound"] and r["sound_again"] for r in res), res
+    assert all(r["lying"].startswith("caught") and r["hanging"].startswith("caught") for r in res), res
