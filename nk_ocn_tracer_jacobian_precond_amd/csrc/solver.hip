@@ -1577,7 +1577,6 @@ extern "C" int nkp_cell_major_order (int64_t nblk, const int32_t *blk_start, int
    if (!blk_start || !perm || !blk_start_new || !col_t || !col_src || cnt < 1 || nblk < 0 || nblk % cnt != 0)
       return fail (NKP_EINVAL, "nkp_cell_major_order: bad arguments (nblk = %lld must be a multiple of the tracer count %d)", (long long) nblk, cnt);
    const int64_t per = nblk / cnt;
-   const int64_t tsl = per ? blk_start[per] - blk_start[0] : 0;
    for (int t = 1; t < cnt; t++)
       for (int64_t c = 0; c <= per; c++)
          if (blk_start[t * per + c] - blk_start[t * per] != blk_start[c] - blk_start[0])
@@ -1592,7 +1591,6 @@ extern "C" int nkp_cell_major_order (int64_t nblk, const int32_t *blk_start, int
          col_t[b] = t;
          col_src[b] = (int32_t) old;
       }
-   (void) tsl;
    return NKP_OK;
 }
 
