@@ -391,6 +391,17 @@ def main():
             if nbytes > 0 and ms > 0:
                 kernels.append({"kernel": label, "bound": "hbm", "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms,
                                 "achieved": nbytes / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS})
+    # HBM bytes per launch of those kernels from the PMC counters (separate rocprofv3 --pmc passes over tools/pmc_cycle.py,
+    # committed under profiles/); attached only when it is this exact workload
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r2_cycle_pmc.json")))
+        if rec.get("n") == n_global and rec.get("nnz") == p.nnz and not distributed:
+            for k in kernels:
+                for q in rec["kernels"]:
+                    if k["kernel"].split("<")[0].split(" ")[0] in q["kernel"] and abs(q["algorithmic_bytes_per_launch"] - k["algorithmic_bytes_per_launch"]) <= 0.01 * k["algorithmic_bytes_per_launch"]:
+                        k["traffic"] = q["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
