@@ -40,10 +40,28 @@
 
 namespace {
 
+// allocator whose resize () leaves the new elements uninitialised: the setup's big arrays are written once by row-parallel
+// loops right after they are sized, and a zero-fill by ONE thread (page faults included) was most of the "twin" time
+template <class T>
+struct RawAlloc {
+   using value_type = T;
+   RawAlloc () = default;
+   template <class U> RawAlloc (const RawAlloc<U> &) {}
+   T *allocate (size_t k) { return static_cast<T *> (::operator new (k * sizeof (T))); }
+   void deallocate (T *q, size_t) { ::operator delete (q); }
+   template <class U> void construct (U *q) noexcept { ::new ((void *) q) U; }                       // default-init: no store for int / double
+   template <class U, class... A> void construct (U *q, A &&... a) { ::new ((void *) q) U (std::forward<A> (a)...); }
+   template <class U> bool operator== (const RawAlloc<U> &) const { return true; }
+   template <class U> bool operator!= (const RawAlloc<U> &) const { return false; }
+};
+using RawInts = std::vector<int, RawAlloc<int>>;
+using RawDoubles = std::vector<double, RawAlloc<double>>;
+
 struct HostCsr {
    int64_t n = 0;
-   std::vector<int> rowptr, colind;
-   std::vector<double> val;
+   std::vector<int> rowptr;
+   RawInts colind;
+   RawDoubles val;
 };
 
 // ---------------------------------------------------------------- host threads for the setup loops
@@ -52,7 +70,9 @@ int setup_threads ()
    static int t = -1;
    if (t < 0) {
       const char *e = getenv ("NKP_SETUP_THREADS");
-      t = e ? atoi (e) : (int) std::min (16u, std::max (1u, std::thread::hardware_concurrency ()));
+      // 1 degree, 256-core host: Galerkin products 0.25 / 0.14 / 0.11 s with 16 / 32 / 64 threads; 32 leaves room for one
+      // process per GPU on an 8-GPU node
+      t = e ? atoi (e) : (int) std::min (32u, std::max (1u, std::thread::hardware_concurrency ()));
       if (t < 1) t = 1;
    }
    return t;
@@ -80,7 +100,8 @@ void for_row_chunks (int64_t n, F fn)
 void build_low_order (int64_t n, const int *rowptr, const int *colind, const double *val, const std::vector<int> &col_of, HostCsr &L)
 {
    const int64_t nnz = rowptr[n];
-   std::vector<double> nv ((size_t) nnz);
+   RawDoubles nv;
+   nv.resize ((size_t) nnz);
    std::vector<int> keep ((size_t) n + 1, 0);
    for_row_chunks (n, [&] (int, int64_t r0, int64_t r1) {
       for (int64_t i = r0; i < r1; i++) {
@@ -525,10 +546,17 @@ void galerkin (const HostCsr &L, const std::vector<int> &cmap, int64_t nc, HostC
    for (int64_t I = 0; I < nc; I++) C.rowptr[I + 1] += C.rowptr[I];
    C.colind.resize ((size_t) C.rowptr[nc]);
    C.val.resize ((size_t) C.rowptr[nc]);
-   for (int t = 0; t < nt_max; t++) {
-      if (last[t] <= first[t]) continue;
-      std::copy (pc[t].begin (), pc[t].end (), C.colind.begin () + C.rowptr[first[t]]);
-      std::copy (pv[t].begin (), pv[t].end (), C.val.begin () + C.rowptr[first[t]]);
+   {
+      // every piece into its place, one thread per piece (the destination pages are first touched here)
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nt_max; t++) {
+         if (last[t] <= first[t]) continue;
+         pool.emplace_back ([&, t] () {
+            std::copy (pc[t].begin (), pc[t].end (), C.colind.begin () + C.rowptr[first[t]]);
+            std::copy (pv[t].begin (), pv[t].end (), C.val.begin () + C.rowptr[first[t]]);
+         });
+      }
+      for (std::thread &th : pool) th.join ();
    }
 }
 
@@ -908,10 +936,13 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
    if (max_levels <= 0) max_levels = 12;
 
    std::vector<Nat> nat;
+   const auto t_begin = clk::now ();
+   double t_host = 0.0;
    {
       SetupTimes T;
       build_nat_levels (nat, n, rowptr, colind, val, blk_start_in, nblk, col_i, col_j, col_t, tracer_cnt, max_levels, coarsest_rows, verbose, rank, T);
       t_low = T.low; t_graph = T.graph; t_galerkin = T.galerkin;
+      t_host = secs (t_begin);
    }
 
    // ---- device levels in colour-major order
@@ -1097,8 +1128,9 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
    }
    if (verbose) {
       printf ("(%d) multilevel setup: %.2f s low-order twin, %.2f s column graphs, %.2f s Galerkin products, %.2f s colour-major permutation, "
-              "%.2f s uploads + factorisation + lane layouts (row blocks %.2f, operator uploads %.2f, column factors %.2f, lane layouts %.2f, transfer maps %.2f)\n",
-              rank, t_low, t_graph, t_galerkin, t_perm, t_dev, t_rb, t_up, t_fac, t_lay, t_map);
+              "%.2f s uploads + factorisation + lane layouts (row blocks %.2f, operator uploads %.2f, column factors %.2f, lane layouts %.2f, transfer maps %.2f); "
+              "host part as a whole %.2f s, everything %.2f s\n",
+              rank, t_low, t_graph, t_galerkin, t_perm, t_dev, t_rb, t_up, t_fac, t_lay, t_map, t_host, secs (t_begin));
       fflush (stdout);
    }
    return 0;
