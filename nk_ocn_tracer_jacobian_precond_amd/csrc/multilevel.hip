@@ -955,9 +955,12 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       const int ncol = (int) N.blk_start.size () - 1;
       V.n = nl;
       // permuted CSR: row new = perm[new]; columns relabelled through inv, then sorted
-      std::vector<int> prow (nl + 1, 0), pcol (N.L.colind.size ());
-      std::vector<double> pval (N.L.colind.size ());
+      std::vector<int> prow (nl + 1, 0);
       auto t_perm0 = clk::now ();
+      RawInts pcol;                                    // sized without a fill: the row-parallel loop below writes every entry
+      RawDoubles pval;
+      pcol.resize (N.L.colind.size ());
+      pval.resize (N.L.colind.size ());
       for (int64_t i = 0; i < nl; i++) prow[i + 1] = prow[i] + (N.L.rowptr[N.perm[i] + 1] - N.L.rowptr[N.perm[i]]);
       for_row_chunks (nl, [&] (int, int64_t i0, int64_t i1) {
          std::vector<std::pair<int, double>> tmp;
@@ -1018,7 +1021,11 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
                 upload (&V.r, (const double *) nullptr, (size_t) nl, &H.device_bytes);
       if (ok) ok = attach_spmv_codes (V.L, prow.data (), pcol.data (), rb.data (), &H.device_bytes) == 0;
       if (ok && H.f32 && l < nlev - 1) {
-         std::vector<float> vf (pval.begin (), pval.begin () + prow[nl]);
+         std::vector<float, RawAlloc<float>> vf;
+         vf.resize ((size_t) prow[nl]);
+         for_row_chunks (nl, [&] (int, int64_t i0, int64_t i1) {
+            for (int64_t e = prow[i0]; e < prow[i1]; e++) vf[(size_t) e] = (float) pval[(size_t) e];
+         });
          ok = upload_padded (&V.L.valf, vf.data (), vf.size (), 2, &H.device_bytes);
       }
       t_up += secs (t_up0);
