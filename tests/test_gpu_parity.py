@@ -745,3 +745,14 @@ def test_device_dense_inverse_matches_host(medium, monkeypatch):
         with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, restart=4) as s:
             z[host] = s.precond_apply(r)
     assert np.array_equal(z["0"], z["1"]), np.abs(z["0"] - z["1"]).max()
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke step (one small solve on cuda:0 checked against the oracle) stays runnable from the test suite."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    importlib.import_module("__graft_entry__").smoke()
