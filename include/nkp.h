@@ -159,6 +159,8 @@ int nkp_multi_dot (nkp_solver *s, const double *V, int64_t ld, int k, const doub
 int nkp_time_kernel (nkp_solver *s, int which, int arg, int reps, double *avg_ms);
 
 /* Introspection: key = "n", "nnz", "nblk", "band", "levels", "spmv_bytes", "device_bytes", "precond_steps", "equil";
+ * "create_us" (wall time of nkp_create), "ml_setup_us" (of which: the hierarchy), "ml_levels_on_device" (levels whose operator
+ * the setup kernels built; the smaller ones are built on the host);
  * compulsory HBM bytes of the pieces nkp_time_kernel times: "smoother_spmv_bytes", "column_solve_bytes", "cycle_bytes";
  * distributed flavour: "dist_overlap" (halo exchange hidden behind the interior rows), "dist_interior_rowblocks",
  * "dist_ras" (hierarchy overlaps the neighbouring ranks), "dist_ras_rows" (rows of other ranks in this rank's hierarchy). */
@@ -277,6 +279,15 @@ void nkp_dist_plan_free (nkp_dist_plan *p);
 int nkp_dist_plan_host (int64_t m_loc, int64_t nnz_loc, const int32_t *rowptr_loc, const int32_t *colind_glob,
                         int rank, int nranks, const int64_t *starts, int32_t *colind_ext, int32_t *halo_rows,
                         int64_t *n_halo, int32_t *need_counts);
+
+/* Introspection of the multilevel hierarchy as it sits on the device (tests: the levels the setup kernels build must equal
+ * the ones the host routines build, entry for entry).  Copies one array of level `level` (0 = finest) to dst and returns its
+ * element count (dst == NULL: the count only); negative = error.  what: "rowptr" (int32, rows + 1), "colind" (int32),
+ * "valf" (float, the f32 storage of a level operator) / "val" (double, where the f64 values are kept), "cmap" (int32: row ->
+ * row of the next level), "rptr" / "ridx" (int32: row of the next level -> its rows here), "blk_start" (int32), "fac"
+ * (double, band factors of the column blocks), "perm0" (int32, level 0: row -> original row), "coarse_inv" (double, last
+ * level).  All in the level's colour-major row order. */
+int64_t nkp_ml_level_array (nkp_solver *s, int level, const char *what, void *dst, int64_t capacity_bytes);
 
 /* Host-only planning step of the multilevel preconditioner inside nkp_create, exposed so the aggregation logic can
  * be tested without a GPU: builds the low-order twin, the coarse cells of every level (geometric groups split by

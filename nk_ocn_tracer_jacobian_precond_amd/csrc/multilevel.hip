@@ -22,6 +22,7 @@
 // Setup is host code (O(nnz)); every cycle runs on the device.
 #include "nkp_dev.h"
 #include "multilevel.h"
+#include "mlsetup.h"
 #include "../../include/nkp.h"
 
 #include <math.h>
@@ -731,33 +732,121 @@ struct Nat {
 
 struct SetupTimes { double low = 0.0, graph = 0.0, galerkin = 0.0; };
 
-// twin, colouring, aggregation and Galerkin product of every level; host only (no HIP call)
-void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, const int *colind, const double *val, const int *blk_start_in, int64_t nblk,
-                       const int *col_i, const int *col_j, const int *col_t, int tracer_cnt, int max_levels, int coarsest_rows, int verbose, int rank, SetupTimes &T)
+// knobs of the hierarchy construction, read once per setup (environment; defaults are the measured best)
+struct PlanKnobs {
+   int split = 1, pocket = 4, big_from = -3;
+   double theta = 0.0, tau = 0.01;
+};
+
+PlanKnobs read_plan_knobs ()
+{
+   PlanKnobs k;
+   const char *e;
+   if ((e = getenv ("NKP_ML_SPLIT"))) k.split = atoi (e) != 0;
+   if ((e = getenv ("NKP_ML_POCKET"))) k.pocket = atoi (e);
+   if ((e = getenv ("NKP_ML_THETA"))) k.theta = atof (e);
+   if ((e = getenv ("NKP_ML_TAU"))) k.tau = atof (e);
+   if ((e = getenv ("NKP_ML_BIG_FROM"))) k.big_from = atoi (e);
+   return k;
+}
+
+// level-0 column arrays (and, with_twin, the low-order twin of A on the host)
+void init_first_nat (Nat &N, int64_t n, const int *rowptr, const int *colind, const double *val, const int *blk_start_in, int64_t nblk,
+                     const int *col_i, const int *col_j, const int *col_t, int tracer_cnt, bool with_twin, SetupTimes &T)
+{
+   using clk = std::chrono::steady_clock;
+   N.blk_start.assign (blk_start_in, blk_start_in + nblk + 1);
+   N.ktop.assign (nblk, 0);
+   if (with_twin) {
+      N.col_of.resize (n);
+      for (int64_t c = 0; c < nblk; c++)
+         for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.col_of[r] = (int) c;
+      auto t0 = clk::now ();
+      build_low_order (n, rowptr, colind, val, N.col_of, N.L);
+      T.low += std::chrono::duration<double> (clk::now () - t0).count ();
+   }
+   if (col_i && col_j) {
+      N.gi.assign (col_i, col_i + nblk);
+      N.gj.assign (col_j, col_j + nblk);
+      N.gt.resize (nblk);
+      const int64_t per = (tracer_cnt > 1 && nblk % tracer_cnt == 0) ? nblk / tracer_cnt : nblk;
+      // tracer of a column: positional (tracer-major rows, src/matrix.c:778-784) unless the caller names it -- the
+      // distributed flavour appends the neighbouring ranks' overlap columns behind its own
+      for (int64_t c = 0; c < nblk; c++) N.gt[c] = col_t ? col_t[c] : (int) (c / per);
+   }
+}
+
+// 2 x 2 blocks of columns in (i, j) (4 x 4 with sh = 2), never across tracers; group ids in order of first member.
+// Returns the number of groups; agg[c] = group of column c, cgi / cgj / cgt = position and tracer of every group.
+int geo_groups (const Nat &N, int sh, std::vector<int> &agg, std::vector<int> &cgi, std::vector<int> &cgj, std::vector<int> &cgt)
+{
+   const int ncol = (int) N.blk_start.size () - 1;
+   std::vector<std::pair<std::array<int, 3>, int>> sorted (ncol);
+   for (int c = 0; c < ncol; c++) sorted[c] = { { N.gt[c], N.gj[c] >> sh, N.gi[c] >> sh }, c };
+   std::sort (sorted.begin (), sorted.end ());
+   std::vector<int> gid_sorted (ncol), first_member;
+   int ng = 0;
+   for (int q = 0; q < ncol; q++) {
+      if (q == 0 || sorted[q].first != sorted[q - 1].first) { first_member.push_back (sorted[q].second); ng++; }
+      gid_sorted[sorted[q].second] = ng - 1;
+   }
+   // renumber groups by their first (lowest natural index) member so coarse columns keep the j, i order
+   std::vector<int> order (ng);
+   std::iota (order.begin (), order.end (), 0);
+   std::sort (order.begin (), order.end (), [&] (int a, int b) { return first_member[a] < first_member[b]; });
+   std::vector<int> newid (ng);
+   for (int q = 0; q < ng; q++) newid[order[q]] = q;
+   agg.resize (ncol);
+   cgi.resize (ng); cgj.resize (ng); cgt.resize (ng);
+   for (int c = 0; c < ncol; c++) {
+      const int a = newid[gid_sorted[c]];
+      agg[c] = a;
+      cgi[a] = N.gi[c] >> sh; cgj[a] = N.gj[c] >> sh; cgt[a] = N.gt[c];
+   }
+   return ng;
+}
+
+// 2 x 2 groups on the big levels, 4 x 4 from level 3 down: every kernel of a small level runs at its latency
+// floor, so fewer small levels pay (1 degree: 8 -> 6 levels, +5 % iterations, -14 % cycle time);
+// NKP_ML_BIG_FROM=l moves the switch, -1 disables it (from level 2 it costs +68 % iterations)
+// (round 2, with the connectivity-aware cells and omega = 1.1: grids of fewer than 200 000 columns per tracer
+// keep the switch at level 3 -- 1 degree: 64 iterations / 0.21 s either way -- larger grids coarsen 2 x 2 all the
+// way, where the better hierarchy outweighs two more latency-bound levels: 0.5 degree 92 -> 79 iterations,
+// 0.95 -> 0.81 s; 0.25 degree 129 -> 105, 4.1 -> 3.4 s)
+int group_shift (const PlanKnobs &K, int level, int ncol_level0, int tracer_cnt)
+{
+   int bf = K.big_from;
+   if (bf == -3) bf = ncol_level0 / (tracer_cnt > 0 ? tracer_cnt : 1) >= 200000 ? -1 : 3;
+   return (bf >= 0 && level >= bf) ? 2 : 1;
+}
+
+// colour of every column and the colour-major row order: newstart[c] = first row of column c in that order
+void colour_major_columns (Nat &N, const std::vector<int> &colour, std::vector<int> &newstart, std::vector<int> &pblk)
+{
+   const int ncol = (int) N.blk_start.size () - 1;
+   newstart.assign (ncol, 0);
+   pblk.clear ();
+   pblk.reserve (ncol + 1);
+   pblk.push_back (0);
+   N.ncol0 = 0;
+   for (int pass = 0; pass < 2; pass++)
+      for (int c = 0; c < ncol; c++)
+         if (colour[c] == pass) {
+            if (pass == 0) N.ncol0++;
+            newstart[c] = pblk.back ();
+            pblk.push_back (pblk.back () + (N.blk_start[c + 1] - N.blk_start[c]));
+         }
+}
+
+// colouring, aggregation and Galerkin product of every level from nat.back () on (which holds its operator); host only
+// (no HIP call).  level0 = index of nat[0] in the whole hierarchy (levels above it were built on the device).
+void extend_nat_levels (std::vector<Nat> &nat, int level0, int ncol_level0, int tracer_cnt, int max_levels, int coarsest_rows, int verbose, int rank,
+                        const PlanKnobs &K, SetupTimes &T)
 {
    using clk = std::chrono::steady_clock;
    auto secs = [] (clk::time_point a) { return std::chrono::duration<double> (clk::now () - a).count (); };
-   double &t_low = T.low, &t_graph = T.graph, &t_galerkin = T.galerkin;
-   nat.assign (1, Nat ());
-   {
-      Nat &N = nat[0];
-      N.blk_start.assign (blk_start_in, blk_start_in + nblk + 1);
-      N.col_of.resize (n);
-      N.ktop.assign (nblk, 0);
-      for (int64_t c = 0; c < nblk; c++)
-         for (int r = N.blk_start[c]; r < N.blk_start[c + 1]; r++) N.col_of[r] = (int) c;
-      { auto t0 = clk::now (); build_low_order (n, rowptr, colind, val, N.col_of, N.L); t_low += secs (t0); }
-      if (col_i && col_j) {
-         N.gi.assign (col_i, col_i + nblk);
-         N.gj.assign (col_j, col_j + nblk);
-         N.gt.resize (nblk);
-         const int64_t per = (tracer_cnt > 1 && nblk % tracer_cnt == 0) ? nblk / tracer_cnt : nblk;
-         // tracer of a column: positional (tracer-major rows, src/matrix.c:778-784) unless the caller names it -- the
-         // distributed flavour appends the neighbouring ranks' overlap columns behind its own
-         for (int64_t c = 0; c < nblk; c++) N.gt[c] = col_t ? col_t[c] : (int) (c / per);
-      }
-   }
-   for (int l = 0;; l++) {
+   double &t_graph = T.graph, &t_galerkin = T.galerkin;
+   for (int l = (int) nat.size () - 1;; l++) {
       Nat &N = nat[l];
       const int ncol = (int) N.blk_start.size () - 1;
       ColGraph G;
@@ -781,48 +870,13 @@ void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, cons
       N.inv.resize (N.L.n);
       for (int64_t i = 0; i < N.L.n; i++) N.inv[N.perm[i]] = (int) i;
 
-      const bool last = (l + 1 >= max_levels) || (N.L.n <= coarsest_rows) || ncol <= 4;
+      const bool last = (level0 + l + 1 >= max_levels) || (N.L.n <= coarsest_rows) || ncol <= 4;
       if (last) break;
       int n2 = 0;
       N.agg.resize (ncol);
       std::vector<int> cgi, cgj, cgt;
       if (geo) {
-         // 2 x 2 blocks of columns in (i, j), never across tracers; ids in order of first member
-         std::vector<std::pair<std::array<int, 3>, int>> keys (ncol);
-         // 2 x 2 on the big levels, 4 x 4 from level 3 down: every kernel of a small level runs at its latency
-         // floor, so fewer small levels pay (1 degree: 8 -> 6 levels, +5 % iterations, -14 % cycle time);
-         // NKP_ML_BIG_FROM=l moves the switch, -1 disables it (from level 2 it costs +68 % iterations)
-         // (round 2, with the connectivity-aware cells and omega = 1.1: grids of fewer than 200 000 columns per tracer
-         // keep the switch at level 3 -- 1 degree: 64 iterations / 0.21 s either way -- larger grids coarsen 2 x 2 all the
-         // way, where the better hierarchy outweighs two more latency-bound levels: 0.5 degree 92 -> 79 iterations,
-         // 0.95 -> 0.81 s; 0.25 degree 129 -> 105, 4.1 -> 3.4 s)
-         static int big_from = -2;
-         if (big_from == -2) { const char *e = getenv ("NKP_ML_BIG_FROM"); big_from = e ? atoi (e) : -3; }
-         int bf = big_from;
-         if (bf == -3) bf = ((int) nat[0].blk_start.size () - 1) / (tracer_cnt > 0 ? tracer_cnt : 1) >= 200000 ? -1 : 3;
-         const int sh = (bf >= 0 && l >= bf) ? 2 : 1;
-         for (int c = 0; c < ncol; c++) keys[c] = { { N.gt[c], N.gj[c] >> sh, N.gi[c] >> sh }, c };
-         std::vector<std::pair<std::array<int, 3>, int>> sorted (keys);
-         std::sort (sorted.begin (), sorted.end ());
-         std::vector<int> gid_sorted (ncol), first_member;
-         int ng = 0;
-         for (int q = 0; q < ncol; q++) {
-            if (q == 0 || sorted[q].first != sorted[q - 1].first) { first_member.push_back (sorted[q].second); ng++; }
-            gid_sorted[sorted[q].second] = ng - 1;
-         }
-         // renumber groups by their first (lowest natural index) member so coarse columns keep the j, i order
-         std::vector<int> order (ng);
-         std::iota (order.begin (), order.end (), 0);
-         std::sort (order.begin (), order.end (), [&] (int a, int b) { return first_member[a] < first_member[b]; });
-         std::vector<int> newid (ng);
-         for (int q = 0; q < ng; q++) newid[order[q]] = q;
-         cgi.resize (ng); cgj.resize (ng); cgt.resize (ng);
-         for (int c = 0; c < ncol; c++) {
-            const int a = newid[gid_sorted[c]];
-            N.agg[c] = a;
-            cgi[a] = N.gi[c] >> sh; cgj[a] = N.gj[c] >> sh; cgt[a] = N.gt[c];
-         }
-         n2 = ng;
+         n2 = geo_groups (N, group_shift (K, level0 + l, ncol_level0, tracer_cnt), N.agg, cgi, cgj, cgt);
       } else {
          // two passes of pairwise matching -> aggregates of up to 4 columns
          std::vector<int> g1, g2;
@@ -835,15 +889,8 @@ void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, cons
       N.nagg = n2;
       Nat C;
       int64_t ncr = 0;
-      static int split = -1, pocket = 4;
-      static double theta = 0.0, tau = 0.01;
-      if (split < 0) {
-         const char *e = getenv ("NKP_ML_SPLIT");
-         split = e ? atoi (e) != 0 : 1;
-         if ((e = getenv ("NKP_ML_POCKET"))) pocket = atoi (e);
-         if ((e = getenv ("NKP_ML_THETA"))) theta = atof (e);
-         if ((e = getenv ("NKP_ML_TAU"))) tau = atof (e);
-      }
+      const int split = K.split, pocket = K.pocket;
+      const double theta = K.theta, tau = K.tau;
       if (geo && split) {
          // connectivity-aware coarse cells inside the geometric groups (see split_aggregate)
          auto t0 = clk::now ();
@@ -853,7 +900,7 @@ void build_nat_levels (std::vector<Nat> &nat, int64_t n, const int *rowptr, cons
          ncr = R.blk_start.back ();
          if (ncr >= N.L.n) break;                       // no coarsening possible
          if (verbose)
-            printf ("(%d) multilevel: level %d -> %d: %d columns in %d groups -> %d coarse columns (%d stubs), %d leaf stubs absorbed\n", rank, l, l + 1, ncol, n2,
+            printf ("(%d) multilevel: level %d -> %d: %d columns in %d groups -> %d coarse columns (%d stubs), %d leaf stubs absorbed\n", rank, level0 + l, level0 + l + 1, ncol, n2,
                     (int) R.blk_start.size () - 1, R.stubs, R.absorbed);
          n2 = (int) R.blk_start.size () - 1;
          N.cmap.swap (R.cmap);
@@ -892,9 +939,11 @@ extern "C" int nkp_ml_plan_host (int64_t n, const int32_t *rowptr, const int32_t
 {
    if (n <= 0 || !rowptr || !colind || !val || !blk_start || nblk <= 0 || !n_levels || !rows || !cmap || !col_of) return NKP_EINVAL;
    if (max_levels <= 0) max_levels = 12;
-   std::vector<Nat> nat;
+   std::vector<Nat> nat (1);
    SetupTimes T;
-   build_nat_levels (nat, n, rowptr, colind, val, blk_start, nblk, col_i, col_j, nullptr, coupled_tracer_cnt, max_levels, coarsest_rows, 0, 0, T);
+   const PlanKnobs K = read_plan_knobs ();
+   init_first_nat (nat[0], n, rowptr, colind, val, blk_start, nblk, col_i, col_j, nullptr, coupled_tracer_cnt, true, T);
+   extend_nat_levels (nat, 0, (int) nblk, coupled_tracer_cnt, max_levels, coarsest_rows, 0, 0, K, T);
    if (getenv ("NKP_ML_PLAN_TIMES")) printf ("nkp_ml_plan_host: %.2f s low-order twin, %.2f s graphs + aggregation, %.2f s Galerkin products\n", T.low, T.graph, T.galerkin);
    *n_levels = (int) nat.size ();
    int64_t qc = 0, qo = 0;
@@ -912,15 +961,330 @@ extern "C" int nkp_ml_plan_host (int64_t n, const int32_t *rowptr, const int32_t
 }
 
 // ================================================================ setup
+namespace {
+
+using setup_clk = std::chrono::steady_clock;
+inline double secs_since (setup_clk::time_point a) { return std::chrono::duration<double> (setup_clk::now () - a).count (); }
+
+struct DevTimes { double rb = 0.0, up = 0.0, fac = 0.0, lay = 0.0, map = 0.0, perm = 0.0, dev = 0.0, twin = 0.0, agg = 0.0, galerkin = 0.0; };
+
+#define ML_FAIL(code, ...) do { snprintf (err, errlen, __VA_ARGS__); return (code); } while (0)
+
+// Column blocks of a level whose colour-major operator is on the device (V.L with f64 values): half bandwidth, band LU of
+// every column, lane layouts; then the f64 values are dropped if the cycle reads the f32 copy.  pblk = row offsets of the
+// columns in colour-major order (host).
+int finish_level_columns (MlHierarchy &H, MlLevel &V, int l, const std::vector<int> &pblk, int ncol, int ncol0, const int *h_prow, hipStream_t st,
+                          char *err, size_t errlen, DevTimes &T)
+{
+   const int64_t nl = V.n;
+   V.B.n = nl;
+   V.B.nblk = ncol;
+   if (!upload (&V.B.blk_start, pblk.data (), pblk.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+   int *dint = nullptr;
+   size_t dummy = 0;
+   std::vector<int> zeros (8, 0);
+   auto t_fac0 = setup_clk::now ();
+   if (!upload (&dint, zeros.data (), 8, &dummy)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+   launch_colblock_measure (V.L, V.B, dint, st);
+   int meas[3];
+   (void) hipMemcpyAsync (meas, dint, sizeof meas, hipMemcpyDeviceToHost, st);
+   (void) hipStreamSynchronize (st);
+   if (meas[1] > 0) { (void) hipFree (dint); ML_FAIL (-4, "multilevel setup: level %d has %d rows without a diagonal entry", l, meas[1]); }
+   V.B.max_len = meas[2];
+   V.B.P = meas[0] <= 1 ? 1 : meas[0] <= 2 ? 2 : 4;
+   if (!upload (&V.B.fac, (const double *) nullptr, (size_t) (2 * V.B.P + 1) * (size_t) nl, &H.device_bytes)) { (void) hipFree (dint); ML_FAIL (-2, "multilevel setup: device allocation failed"); }
+   (void) hipMemsetAsync (dint, 0, 8 * sizeof (int), st);
+   launch_colblock_factor (V.L, V.B, dint, st);
+   int st2[2];
+   (void) hipMemcpyAsync (st2, dint, sizeof st2, hipMemcpyDeviceToHost, st);
+   (void) hipStreamSynchronize (st);
+   (void) hipFree (dint);
+   if (st2[0] != 0) ML_FAIL (-4, "multilevel setup: zero pivot in a column block of level %d (row %d)", l, st2[0] - 1);
+   V.B.dropped = st2[1];
+   T.fac += secs_since (t_fac0);
+   {
+      auto t_lay0 = setup_clk::now ();
+      const int ranges[3] = { 0, ncol0, ncol };
+      const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st, H.f32, H.fused ? h_prow : nullptr);
+      if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
+      static int wave_max = -1;
+      if (wave_max < 0) { const char *e = getenv ("NKP_COLWAVE_MAX"); wave_max = e ? atoi (e) : 8192; }
+      V.wave_columns = ncol <= wave_max && V.B.dropped == 0;
+      T.lay += secs_since (t_lay0);
+   }
+   // f32 storage mode: the f64 copy of the level operator was only needed to factor the column blocks
+   if (V.L.valf && V.L.val) {
+      (void) hipStreamSynchronize (st);
+      (void) hipFree (V.L.val);
+      V.L.val = nullptr;
+      H.device_bytes -= ((size_t) V.L.nnz + 2) * sizeof (double);
+   }
+   return 0;
+}
+
+// one level from host arrays (natural order in N, next level in C or NULL): colour-major operator, uploads, column blocks,
+// transfer maps, dense inverse of the last level
+int finalize_host_level (MlHierarchy &H, int l, int nlev, Nat &N, Nat *Cn, int verbose, int rank, hipStream_t st, char *err, size_t errlen, DevTimes &T)
+{
+   MlLevel &V = H.lev[l];
+   const int64_t nl = N.L.n;
+   const int ncol = (int) N.blk_start.size () - 1;
+   V.n = nl;
+   // permuted CSR: row new = perm[new]; columns relabelled through inv, then sorted
+   std::vector<int> prow (nl + 1, 0);
+   auto t_perm0 = setup_clk::now ();
+   RawInts pcol;                                    // sized without a fill: the row-parallel loop below writes every entry
+   RawDoubles pval;
+   pcol.resize (N.L.colind.size ());
+   pval.resize (N.L.colind.size ());
+   for (int64_t i = 0; i < nl; i++) prow[i + 1] = prow[i] + (N.L.rowptr[N.perm[i] + 1] - N.L.rowptr[N.perm[i]]);
+   for_row_chunks (nl, [&] (int, int64_t i0, int64_t i1) {
+      std::vector<std::pair<int, double>> tmp;
+      for (int64_t i = i0; i < i1; i++) {
+         const int o = N.perm[i];
+         tmp.clear ();
+         for (int e = N.L.rowptr[o]; e < N.L.rowptr[o + 1]; e++) tmp.emplace_back (N.inv[N.L.colind[e]], N.L.val[e]);
+         std::sort (tmp.begin (), tmp.end ());
+         int q = prow[i];
+         for (auto &t : tmp) { pcol[q] = t.first; pval[q] = t.second; q++; }
+      }
+   });
+   T.perm += secs_since (t_perm0);
+   auto t_dev0 = setup_clk::now ();
+   // permuted column blocks
+   std::vector<int> pblk;
+   pblk.reserve (ncol + 1);
+   pblk.push_back (0);
+   for (int pass = 0; pass < 2; pass++)
+      for (int c = 0; c < ncol; c++)
+         if (N.colour[c] == pass) pblk.push_back (pblk.back () + (N.blk_start[c + 1] - N.blk_start[c]));
+   V.color_blk[0] = 0;
+   V.color_blk[1] = N.ncol0;
+   V.color_blk[2] = ncol;
+   const int rows0 = pblk[N.ncol0];
+   V.rows0 = rows0;
+   // row blocks per colour (must not straddle the colour boundary)
+   int *rb0 = nullptr, *rb1 = nullptr, nrb0 = 0, nrb1 = 0;
+   auto t_rb0 = setup_clk::now ();
+   build_rowblocks_host (rows0, prow.data (), &rb0, &nrb0);
+   {
+      std::vector<int> shifted (nl - rows0 + 1);
+      for (int64_t i = rows0; i <= nl; i++) shifted[i - rows0] = prow[i] - prow[rows0];
+      build_rowblocks_host (nl - rows0, shifted.data (), &rb1, &nrb1);
+   }
+   std::vector<int> rb (nrb0 + nrb1 + 1);
+   for (int i = 0; i <= nrb0; i++) rb[i] = rb0[i];
+   for (int i = 1; i <= nrb1; i++) rb[nrb0 + i] = rows0 + rb1[i];
+   if (nl - rows0 == 0) nrb1 = 0;
+   if (rows0 == 0) { nrb0 = 0; }
+   free (rb0);
+   free (rb1);
+   V.color_rb[0] = 0;
+   V.color_rb[1] = nrb0;
+   V.color_rb[2] = nrb0 + nrb1;
+   V.L.n = nl;
+   V.L.nnz = prow[nl];
+   V.L.nrowblk = nrb0 + nrb1;
+   T.rb += secs_since (t_rb0);
+   auto t_up0 = setup_clk::now ();
+   bool ok = upload (&V.L.rowptr, prow.data (), (size_t) nl + 1, &H.device_bytes) &&
+             upload_padded (&V.L.colind, pcol.data (), (size_t) prow[nl], 2, &H.device_bytes) &&
+             upload_padded (&V.L.val, pval.data (), (size_t) prow[nl], 2, &H.device_bytes) &&
+             upload (&V.L.rowblk, rb.data (), rb.size (), &H.device_bytes) &&
+             upload (&V.x, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
+             upload (&V.x2, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
+             upload (&V.b, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
+             upload (&V.r, (const double *) nullptr, (size_t) nl, &H.device_bytes);
+   if (ok) ok = attach_spmv_codes (V.L, prow.data (), pcol.data (), rb.data (), &H.device_bytes) == 0;
+   if (ok && H.f32 && l < nlev - 1) {
+      std::vector<float, RawAlloc<float>> vf;
+      vf.resize ((size_t) prow[nl]);
+      for_row_chunks (nl, [&] (int, int64_t i0, int64_t i1) {
+         for (int64_t e = prow[i0]; e < prow[i1]; e++) vf[(size_t) e] = (float) pval[(size_t) e];
+      });
+      ok = upload_padded (&V.L.valf, vf.data (), vf.size (), 2, &H.device_bytes);
+   }
+   T.up += secs_since (t_up0);
+   if (!ok) ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l);
+   if (l == 0 && !upload (&H.perm0, N.perm.data (), (size_t) nl, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+
+   static int dense_max = -1;
+   if (dense_max < 0) { const char *e = getenv ("NKP_ML_DENSE_MAX"); dense_max = e ? atoi (e) : 6000; }
+   // the last level is solved with a dense inverse when it is small enough; otherwise (rough bathymetry can leave
+   // thousands of pocket stubs that nothing absorbs) it is relaxed like the others, with many sweeps
+   const bool dense_last = (l == nlev - 1) && nl <= dense_max;
+   if (!dense_last) {
+      const int frc = finish_level_columns (H, V, l, pblk, ncol, N.ncol0, prow.data (), st, err, errlen, T);
+      if (frc) return frc;
+   }
+   if (l < nlev - 1) {
+      // transfer operators in permuted orders
+      auto t_map0 = setup_clk::now ();
+      Nat &C = *Cn;
+      const int64_t nc = C.L.n;
+      V.nc = nc;
+      std::vector<int> cmap_p (nl);
+      for (int64_t i = 0; i < nl; i++) cmap_p[i] = C.inv[N.cmap[N.perm[i]]];
+      std::vector<int> rptr (nc + 1, 0), ridx (nl);
+      for (int64_t i = 0; i < nl; i++) rptr[cmap_p[i] + 1]++;
+      for (int64_t I = 0; I < nc; I++) rptr[I + 1] += rptr[I];
+      {
+         std::vector<int> fill (rptr.begin (), rptr.end () - 1);
+         for (int64_t i = 0; i < nl; i++) ridx[fill[cmap_p[i]]++] = (int) i;
+      }
+      if (!(upload (&V.cmap, cmap_p.data (), (size_t) nl, &H.device_bytes) && upload (&V.rptr, rptr.data (), (size_t) nc + 1, &H.device_bytes) &&
+            upload (&V.ridx, ridx.data (), (size_t) nl, &H.device_bytes)))
+         ML_FAIL (-2, "multilevel setup: device allocation failed");
+      T.map += secs_since (t_map0);
+   }
+   if (dense_last) {
+      // coarsest level: dense inverse (permuted order)
+      std::vector<double> dense ((size_t) nl * nl, 0.0);
+      for (int64_t i = 0; i < nl; i++)
+         for (int e = prow[i]; e < prow[i + 1]; e++) dense[(size_t) i * nl + pcol[e]] = pval[e];
+      static int host_inverse = -1;
+      if (host_inverse < 0) { const char *e = getenv ("NKP_ML_HOST_INVERSE"); host_inverse = e ? atoi (e) != 0 : 0; }
+      if (host_inverse) {
+         if (!dense_inverse ((int) nl, dense)) ML_FAIL (-4, "multilevel setup: coarsest operator is singular");
+         if (!upload (&H.coarse_inv, dense.data (), dense.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+      } else if (!dense_inverse_device ((int) nl, dense, &H.coarse_inv, &H.device_bytes, st))
+         ML_FAIL (-4, "multilevel setup: coarsest operator is singular (or the device is out of memory)");
+   }
+   if (verbose)
+      printf ("(%d) multilevel: level %d: %lld rows, %lld entries, %d columns (%d + %d by colour)%s\n", rank, l, (long long) nl,
+              (long long) prow[nl], ncol, N.ncol0, ncol - N.ncol0, l < nlev - 1 ? "" : dense_last ? ", dense solve" : ", relaxed (too large for a dense inverse)");
+   T.dev += secs_since (t_dev0);
+   return 0;
+}
+
+// ---- levels whose operator is built on the device (mlsetup.hip)
+struct DevLevel {
+   mls::DevCsr L;                                                     // natural order
+   int *blk_start = nullptr, *col_of = nullptr, *ktop = nullptr;      // per column / per row / per column
+   int *perm = nullptr, *inv = nullptr;                               // colour-major maps
+   int *cmap = nullptr;                                               // natural row -> natural row of the next level
+   std::vector<int> newstart, pblk;                                   // host: colour-major start row of every column, permuted blocks
+   void free_all ()
+   {
+      L.free_all ();
+      for (int **p : { &blk_start, &col_of, &ktop, &perm, &inv, &cmap })
+         if (*p) { (void) hipFree (*p); *p = nullptr; }
+   }
+};
+
+// column arrays of a level on the device + its colour-major maps; N holds the host column arrays (blk_start, ktop, gi, gj)
+int dev_level_columns (DevLevel &D, Nat &N, int64_t n, hipStream_t st)
+{
+   const int ncol = (int) N.blk_start.size () - 1;
+   size_t dummy = 0;
+   N.colour.resize (ncol);
+   for (int c = 0; c < ncol; c++) N.colour[c] = (N.gi[c] + N.gj[c]) & 1;
+   colour_major_columns (N, N.colour, D.newstart, D.pblk);
+   int *d_newstart = nullptr;
+   bool ok = upload (&D.blk_start, N.blk_start.data (), (size_t) ncol + 1, &dummy) && upload (&D.ktop, N.ktop.data (), (size_t) ncol, &dummy) &&
+             upload (&D.col_of, (const int *) nullptr, (size_t) n, &dummy) && upload (&D.perm, (const int *) nullptr, (size_t) n, &dummy) &&
+             upload (&D.inv, (const int *) nullptr, (size_t) n, &dummy) && upload (&d_newstart, D.newstart.data (), (size_t) ncol, &dummy);
+   if (!ok) { if (d_newstart) (void) hipFree (d_newstart); return 1; }
+   mls::rows_to_cols (D.blk_start, ncol, D.col_of, st);
+   mls::colour_major_maps (D.blk_start, D.col_of, d_newstart, n, D.perm, D.inv, st);
+   const hipError_t e = hipStreamSynchronize (st);
+   (void) hipFree (d_newstart);
+   return e == hipSuccess ? 0 : 1;
+}
+
+// a level that has a coarser one, from its device-resident natural operator: colour-major operator, row blocks, f32 copy,
+// column blocks, transfer maps.  inv_next = colour-major map of the next level (device).
+int finalize_device_level (MlHierarchy &H, int l, DevLevel &D, Nat &N, const int *inv_next, int64_t nc, int verbose, int rank, hipStream_t st,
+                           char *err, size_t errlen, DevTimes &T)
+{
+   MlLevel &V = H.lev[l];
+   const int64_t nl = D.L.n;
+   const int ncol = (int) N.blk_start.size () - 1;
+   V.n = nl;
+   auto t0 = setup_clk::now ();
+   int *prow = nullptr, *pcol = nullptr;
+   double *pval = nullptr;
+   int rc = mls::permute_operator (D.L, D.perm, D.inv, &prow, &pcol, &pval, 2, st);
+   if (rc) ML_FAIL (-2, "multilevel setup: colour-major operator of level %d failed on the device (HIP error %d)", l, rc);
+   V.L.n = nl;
+   V.L.nnz = D.L.nnz;
+   V.L.rowptr = prow;
+   V.L.colind = pcol;
+   V.L.val = pval;
+   H.device_bytes += ((size_t) nl + 1) * sizeof (int) + ((size_t) D.L.nnz + 2) * (sizeof (int) + sizeof (double));
+   T.perm += secs_since (t0);
+   t0 = setup_clk::now ();
+   V.color_blk[0] = 0;
+   V.color_blk[1] = N.ncol0;
+   V.color_blk[2] = ncol;
+   const int rows0 = D.pblk[N.ncol0];
+   V.rows0 = rows0;
+   {
+      // row blocks per colour (must not straddle the colour boundary)
+      int *rb0 = nullptr, *rb1 = nullptr, nrb0 = 0, nrb1 = 0;
+      if ((rc = mls::row_blocks (prow, 0, rows0, &rb0, &nrb0, st)) || (rc = mls::row_blocks (prow, rows0, nl, &rb1, &nrb1, st))) {
+         if (rb0) (void) hipFree (rb0);
+         ML_FAIL (-2, "multilevel setup: row blocks of level %d failed on the device (HIP error %d)", l, rc);
+      }
+      int *rb = nullptr;
+      bool ok = hipMalloc ((void **) &rb, (size_t) (nrb0 + nrb1 + 1) * sizeof (int)) == hipSuccess;
+      if (ok && nrb0) ok = hipMemcpyAsync (rb, rb0, (size_t) nrb0 * sizeof (int), hipMemcpyDeviceToDevice, st) == hipSuccess;
+      if (ok && nrb1) ok = hipMemcpyAsync (rb + nrb0, rb1, (size_t) (nrb1 + 1) * sizeof (int), hipMemcpyDeviceToDevice, st) == hipSuccess;
+      if (ok && !nrb1) { const int last = (int) nl; ok = hipMemcpyAsync (rb + nrb0, &last, sizeof (int), hipMemcpyHostToDevice, st) == hipSuccess; }
+      if (ok) ok = hipStreamSynchronize (st) == hipSuccess;
+      if (rb0) (void) hipFree (rb0);
+      if (rb1) (void) hipFree (rb1);
+      if (!ok) { if (rb) (void) hipFree (rb); ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l); }
+      V.L.rowblk = rb;
+      V.L.nrowblk = nrb0 + nrb1;
+      V.color_rb[0] = 0;
+      V.color_rb[1] = nrb0;
+      V.color_rb[2] = nrb0 + nrb1;
+      H.device_bytes += (size_t) (nrb0 + nrb1 + 1) * sizeof (int);
+   }
+   T.rb += secs_since (t0);
+   t0 = setup_clk::now ();
+   bool ok = upload (&V.x, (const double *) nullptr, (size_t) nl, &H.device_bytes) && upload (&V.x2, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
+             upload (&V.b, (const double *) nullptr, (size_t) nl, &H.device_bytes) && upload (&V.r, (const double *) nullptr, (size_t) nl, &H.device_bytes);
+   if (ok && H.f32) {
+      ok = upload (&V.L.valf, (const float *) nullptr, (size_t) D.L.nnz + 2, &H.device_bytes) &&
+           hipMemsetAsync (V.L.valf + D.L.nnz, 0, 2 * sizeof (float), st) == hipSuccess;
+      if (ok) mls::to_float (pval, V.L.valf, D.L.nnz, st);
+   }
+   if (!ok) ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l);
+   if (l == 0) {
+      // level-0 row i holds original row perm0[i]
+      if (!upload (&H.perm0, (const int *) nullptr, (size_t) nl, &H.device_bytes) ||
+          hipMemcpyAsync (H.perm0, D.perm, (size_t) nl * sizeof (int), hipMemcpyDeviceToDevice, st) != hipSuccess)
+         ML_FAIL (-2, "multilevel setup: device allocation failed");
+   }
+   T.up += secs_since (t0);
+   const int frc = finish_level_columns (H, V, l, D.pblk, ncol, N.ncol0, nullptr, st, err, errlen, T);
+   if (frc) return frc;
+   {
+      // transfer operators in colour-major orders
+      t0 = setup_clk::now ();
+      V.nc = nc;
+      if (!upload (&V.cmap, (const int *) nullptr, (size_t) nl, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+      mls::permuted_cmap (D.cmap, D.perm, inv_next, nl, V.cmap, st);
+      if ((rc = mls::inverse_map (V.cmap, nl, nc, &V.rptr, &V.ridx, st))) ML_FAIL (-2, "multilevel setup: transfer maps of level %d failed on the device (HIP error %d)", l, rc);
+      H.device_bytes += ((size_t) nc + 1 + (size_t) nl) * sizeof (int);
+      T.map += secs_since (t0);
+   }
+   if (verbose)
+      printf ("(%d) multilevel: level %d: %lld rows, %lld entries, %d columns (%d + %d by colour), built on the device\n", rank, l, (long long) nl,
+              (long long) D.L.nnz, ncol, N.ncol0, ncol - N.ncol0);
+   return 0;
+}
+
+}  // namespace
+
 int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, const double *val,
               const int *blk_start_in, int64_t nblk, const int *col_i, const int *col_j, const int *col_t, int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
-              hipStream_t st, char *err, size_t errlen)
+              hipStream_t st, char *err, size_t errlen, const CsrDev *A_dev)
 {
-#define ML_FAIL(code, ...) do { snprintf (err, errlen, __VA_ARGS__); return (code); } while (0)
-   using clk = std::chrono::steady_clock;
-   auto secs = [] (clk::time_point a) { return std::chrono::duration<double> (clk::now () - a).count (); };
-   double t_low = 0.0, t_graph = 0.0, t_galerkin = 0.0, t_perm = 0.0, t_dev = 0.0;
-   double t_rb = 0.0, t_up = 0.0, t_fac = 0.0, t_lay = 0.0, t_map = 0.0;      // pieces of t_dev
+   DevTimes T;
+   SetupTimes TH;
    H.nu = nu < 1 ? 1 : nu;
    H.f32 = 1;                                     // level operators and factors stored in f32, arithmetic in f64
    if (const char *e = getenv ("NKP_ML_F32")) H.f32 = atoi (e) != 0;
@@ -934,191 +1298,144 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
    if (const char *e = getenv ("NKP_ML_SMOOTH_COARSE")) { const int v = atoi (e); if (v >= 1) H.nu_coarse = v; }
    if (const char *e = getenv ("NKP_ML_COARSE_FROM")) { const int v = atoi (e); if (v >= 1) H.coarse_from = v; }
    if (max_levels <= 0) max_levels = 12;
+   const PlanKnobs K = read_plan_knobs ();
+   const auto t_begin = setup_clk::now ();
 
-   std::vector<Nat> nat;
-   const auto t_begin = clk::now ();
-   double t_host = 0.0;
-   {
-      SetupTimes T;
-      build_nat_levels (nat, n, rowptr, colind, val, blk_start_in, nblk, col_i, col_j, col_t, tracer_cnt, max_levels, coarsest_rows, verbose, rank, T);
-      t_low = T.low; t_graph = T.graph; t_galerkin = T.galerkin;
-      t_host = secs (t_begin);
-   }
+   // Levels with at least dev_min rows are built by the kernels of mlsetup.hip, the rest by the host routines above (a
+   // level of a few 10^4 rows costs less on the host than the launches and round trips of the device passes); both build
+   // the same hierarchy entry for entry.  The device passes cover the default construction only: geometric groups with
+   // connectivity-aware cells, no edge threshold, no 2-byte column codes, no fused half sweeps.
+   int64_t dev_min = 100000;
+   if (const char *e = getenv ("NKP_ML_DEVICE_MIN")) dev_min = atoll (e);
+   const bool codes = getenv ("NKP_SPMV_COMPRESS") && atoi (getenv ("NKP_SPMV_COMPRESS")) != 0;
+   const bool device_ok = col_i && col_j && K.split && K.theta == 0.0 && !codes && !H.fused && dev_min >= 0;
 
-   // ---- device levels in colour-major order
-   const int nlev = (int) nat.size ();
-   H.lev.resize (nlev);
-   for (int l = 0; l < nlev; l++) {
-      Nat &N = nat[l];
-      MlLevel &V = H.lev[l];
-      const int64_t nl = N.L.n;
-      const int ncol = (int) N.blk_start.size () - 1;
-      V.n = nl;
-      // permuted CSR: row new = perm[new]; columns relabelled through inv, then sorted
-      std::vector<int> prow (nl + 1, 0);
-      auto t_perm0 = clk::now ();
-      RawInts pcol;                                    // sized without a fill: the row-parallel loop below writes every entry
-      RawDoubles pval;
-      pcol.resize (N.L.colind.size ());
-      pval.resize (N.L.colind.size ());
-      for (int64_t i = 0; i < nl; i++) prow[i + 1] = prow[i] + (N.L.rowptr[N.perm[i] + 1] - N.L.rowptr[N.perm[i]]);
-      for_row_chunks (nl, [&] (int, int64_t i0, int64_t i1) {
-         std::vector<std::pair<int, double>> tmp;
-         for (int64_t i = i0; i < i1; i++) {
-            const int o = N.perm[i];
-            tmp.clear ();
-            for (int e = N.L.rowptr[o]; e < N.L.rowptr[o + 1]; e++) tmp.emplace_back (N.inv[N.L.colind[e]], N.L.val[e]);
-            std::sort (tmp.begin (), tmp.end ());
-            int q = prow[i];
-            for (auto &t : tmp) { pcol[q] = t.first; pval[q] = t.second; q++; }
-         }
-      });
-      t_perm += secs (t_perm0);
-      auto t_dev0 = clk::now ();
-      // permuted column blocks
-      std::vector<int> pblk;
-      pblk.reserve (ncol + 1);
-      pblk.push_back (0);
-      for (int pass = 0; pass < 2; pass++)
-         for (int c = 0; c < ncol; c++)
-            if (N.colour[c] == pass) pblk.push_back (pblk.back () + (N.blk_start[c + 1] - N.blk_start[c]));
-      V.color_blk[0] = 0;
-      V.color_blk[1] = N.ncol0;
-      V.color_blk[2] = ncol;
-      const int rows0 = pblk[N.ncol0];
-      V.rows0 = rows0;
-      // row blocks per colour (must not straddle the colour boundary)
-      int *rb0 = nullptr, *rb1 = nullptr, nrb0 = 0, nrb1 = 0;
-      auto t_rb0 = clk::now ();
-      build_rowblocks_host (rows0, prow.data (), &rb0, &nrb0);
+   std::vector<Nat> hnat;              // host-built levels (the first of them may have been handed over by the device path)
+   int l0 = 0;                         // index of hnat[0] in the hierarchy
+   int ndev_levels = 0;
+   if (device_ok && n >= dev_min && !((1 >= max_levels) || (n <= coarsest_rows) || nblk <= 4)) {
+      // ---------------- device path
+      DevLevel D;
+      Nat N;
+      init_first_nat (N, n, rowptr, colind, val, blk_start_in, nblk, col_i, col_j, col_t, tracer_cnt, false, TH);
+      N.L.n = n;
+      size_t dummy = 0;
       {
-         std::vector<int> shifted (nl - rows0 + 1);
-         for (int64_t i = rows0; i <= nl; i++) shifted[i - rows0] = prow[i] - prow[rows0];
-         build_rowblocks_host (nl - rows0, shifted.data (), &rb1, &nrb1);
+         // the matrix: the caller's device copy when there is one, else a temporary upload
+         auto t0 = setup_clk::now ();
+         int *a_row = nullptr, *a_col = nullptr;
+         double *a_val = nullptr;
+         const int nnz = rowptr[n];
+         if (!A_dev) {
+            if (!(upload (&a_row, rowptr, (size_t) n + 1, &dummy) && upload (&a_col, colind, (size_t) nnz, &dummy) && upload (&a_val, val, (size_t) nnz, &dummy))) {
+               for (void *p : { (void *) a_row, (void *) a_col, (void *) a_val }) if (p) (void) hipFree (p);
+               ML_FAIL (-2, "multilevel setup: device allocation failed");
+            }
+         }
+         int rc = dev_level_columns (D, N, n, st);
+         if (!rc) rc = mls::twin (n, A_dev ? A_dev->rowptr : a_row, A_dev ? A_dev->colind : a_col, A_dev ? A_dev->val : a_val, D.col_of, D.L, st);
+         for (void *p : { (void *) a_row, (void *) a_col, (void *) a_val }) if (p) (void) hipFree (p);
+         if (rc) { D.free_all (); ML_FAIL (-2, "multilevel setup: low-order twin failed on the device (HIP error %d)", rc); }
+         T.twin += secs_since (t0);
       }
-      std::vector<int> rb (nrb0 + nrb1 + 1);
-      for (int i = 0; i <= nrb0; i++) rb[i] = rb0[i];
-      for (int i = 1; i <= nrb1; i++) rb[nrb0 + i] = rows0 + rb1[i];
-      if (nl - rows0 == 0) nrb1 = 0;
-      if (rows0 == 0) { nrb0 = 0; }
-      free (rb0);
-      free (rb1);
-      V.color_rb[0] = 0;
-      V.color_rb[1] = nrb0;
-      V.color_rb[2] = nrb0 + nrb1;
-      V.L.n = nl;
-      V.L.nnz = prow[nl];
-      V.L.nrowblk = nrb0 + nrb1;
-      t_rb += secs (t_rb0);
-      auto t_up0 = clk::now ();
-      bool ok = upload (&V.L.rowptr, prow.data (), (size_t) nl + 1, &H.device_bytes) &&
-                upload_padded (&V.L.colind, pcol.data (), (size_t) prow[nl], 2, &H.device_bytes) &&
-                upload_padded (&V.L.val, pval.data (), (size_t) prow[nl], 2, &H.device_bytes) &&
-                upload (&V.L.rowblk, rb.data (), rb.size (), &H.device_bytes) &&
-                upload (&V.x, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
-                upload (&V.x2, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
-                upload (&V.b, (const double *) nullptr, (size_t) nl, &H.device_bytes) &&
-                upload (&V.r, (const double *) nullptr, (size_t) nl, &H.device_bytes);
-      if (ok) ok = attach_spmv_codes (V.L, prow.data (), pcol.data (), rb.data (), &H.device_bytes) == 0;
-      if (ok && H.f32 && l < nlev - 1) {
-         std::vector<float, RawAlloc<float>> vf;
-         vf.resize ((size_t) prow[nl]);
-         for_row_chunks (nl, [&] (int, int64_t i0, int64_t i1) {
-            for (int64_t e = prow[i0]; e < prow[i1]; e++) vf[(size_t) e] = (float) pval[(size_t) e];
-         });
-         ok = upload_padded (&V.L.valf, vf.data (), vf.size (), 2, &H.device_bytes);
+      for (int l = 0;; l++) {
+         // D / N = level l, resident on the device, with a coarser level to come unless the aggregation stalls
+         const int ncol = (int) N.blk_start.size () - 1;
+         std::vector<int> cgi, cgj, cgt;
+         const int ng = geo_groups (N, group_shift (K, l, (int) nblk, tracer_cnt), N.agg, cgi, cgj, cgt);
+         N.nagg = ng;
+         auto t0 = setup_clk::now ();
+         mls::AggregateIn ain;
+         ain.n = D.L.n; ain.ncol = ncol;
+         ain.rowptr = D.L.rowptr; ain.colind = D.L.colind; ain.val = D.L.val;
+         ain.blk_start = D.blk_start; ain.col_of = D.col_of; ain.ktop = D.ktop;
+         ain.h_blk_start = N.blk_start.data (); ain.h_ktop = N.ktop.data (); ain.h_group = N.agg.data (); ain.h_col_t = N.gt.data ();
+         ain.pocket = K.pocket; ain.tau = K.tau;
+         mls::AggregateOut aout;
+         int rc = mls::aggregate (ain, aout, st);
+         if (rc) { D.free_all (); ML_FAIL (-2, "multilevel setup: aggregation of level %d failed on the device (HIP error %d)", l, rc); }
+         T.agg += secs_since (t0);
+         D.cmap = aout.cmap;
+         const int64_t ncr = aout.blk_start.back ();
+         Nat C;
+         DevLevel DC;
+         bool stalled = ncr >= D.L.n;                  // no coarsening possible: level l is the last one
+         if (!stalled) {
+            if (verbose)
+               printf ("(%d) multilevel: level %d -> %d: %d columns in %d groups -> %d coarse columns (%d stubs), %d leaf stubs absorbed\n", rank, l, l + 1, ncol, ng,
+                       (int) aout.blk_start.size () - 1, aout.stubs, aout.absorbed);
+            const int ncc = (int) aout.blk_start.size () - 1;
+            C.blk_start.swap (aout.blk_start);
+            C.ktop.swap (aout.ktop);
+            C.gi.resize (ncc); C.gj.resize (ncc); C.gt.resize (ncc);
+            for (int q = 0; q < ncc; q++) { const int g = aout.group[q]; C.gi[q] = cgi[g]; C.gj[q] = cgj[g]; C.gt[q] = cgt[g]; }
+            t0 = setup_clk::now ();
+            rc = mls::galerkin (D.L, D.cmap, ncr, DC.L, st);
+            if (!rc) rc = dev_level_columns (DC, C, ncr, st);
+            if (rc) { D.free_all (); DC.free_all (); ML_FAIL (-2, "multilevel setup: Galerkin product of level %d failed on the device (HIP error %d)", l, rc); }
+            C.L.n = ncr;
+            T.galerkin += secs_since (t0);
+         }
+         // what becomes of the next level (or of this one, if it is the last): handed to the host routines when it is small
+         // or final
+         const bool next_last = stalled || (l + 2 >= max_levels) || (ncr <= coarsest_rows) || (int) C.blk_start.size () - 1 <= 4;
+         const bool hand_over = stalled || next_last || ncr < dev_min;
+         if (!stalled) {
+            H.lev.resize ((size_t) l + 1);
+            const int frc = finalize_device_level (H, l, D, N, DC.inv, ncr, verbose, rank, st, err, errlen, T);
+            if (frc) { D.free_all (); DC.free_all (); return frc; }
+            ndev_levels = l + 1;
+         }
+         if (hand_over) {
+            // download the natural operator of the level the host continues from
+            DevLevel &S = stalled ? D : DC;
+            Nat &M = stalled ? N : C;
+            M.L.n = S.L.n;
+            M.L.rowptr.resize ((size_t) S.L.n + 1);
+            M.L.colind.resize ((size_t) S.L.nnz);
+            M.L.val.resize ((size_t) S.L.nnz);
+            bool ok = hipMemcpy (M.L.rowptr.data (), S.L.rowptr, ((size_t) S.L.n + 1) * sizeof (int), hipMemcpyDeviceToHost) == hipSuccess;
+            if (ok && S.L.nnz) ok = hipMemcpy (M.L.colind.data (), S.L.colind, (size_t) S.L.nnz * sizeof (int), hipMemcpyDeviceToHost) == hipSuccess &&
+                                    hipMemcpy (M.L.val.data (), S.L.val, (size_t) S.L.nnz * sizeof (double), hipMemcpyDeviceToHost) == hipSuccess;
+            const int ncm = (int) M.blk_start.size () - 1;
+            M.col_of.resize ((size_t) S.L.n);
+            for (int c = 0; c < ncm; c++)
+               for (int r = M.blk_start[c]; r < M.blk_start[c + 1]; r++) M.col_of[r] = c;
+            M.colour.clear (); M.agg.clear ();
+            l0 = stalled ? l : l + 1;
+            hnat.clear ();
+            hnat.push_back (std::move (M));
+            D.free_all ();
+            DC.free_all ();
+            if (!ok) ML_FAIL (-3, "multilevel setup: download of level %d failed", l0);
+            if (!stalled && !next_last) extend_nat_levels (hnat, l0, (int) nblk, tracer_cnt, max_levels, coarsest_rows, verbose, rank, K, TH);
+            else {
+               // a final level: only its colour-major order is missing
+               std::vector<Nat> one;
+               one.push_back (std::move (hnat[0]));
+               extend_nat_levels (one, l0, (int) nblk, tracer_cnt, l0 + 1, coarsest_rows, verbose, rank, K, TH);
+               hnat.swap (one);
+            }
+            break;
+         }
+         D.free_all ();
+         D = DC;                    // plain struct of pointers + two vectors
+         DC = DevLevel ();
+         N = std::move (C);
       }
-      t_up += secs (t_up0);
-      if (!ok) ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l);
-      if (l == 0 && !upload (&H.perm0, N.perm.data (), (size_t) nl, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+   } else {
+      hnat.resize (1);
+      init_first_nat (hnat[0], n, rowptr, colind, val, blk_start_in, nblk, col_i, col_j, col_t, tracer_cnt, true, TH);
+      extend_nat_levels (hnat, 0, (int) nblk, tracer_cnt, max_levels, coarsest_rows, verbose, rank, K, TH);
+   }
+   const double t_plan = secs_since (t_begin);
 
-      static int dense_max = -1;
-      if (dense_max < 0) { const char *e = getenv ("NKP_ML_DENSE_MAX"); dense_max = e ? atoi (e) : 6000; }
-      // the last level is solved with a dense inverse when it is small enough; otherwise (rough bathymetry can leave
-      // thousands of pocket stubs that nothing absorbs) it is relaxed like the others, with many sweeps
-      const bool dense_last = (l == nlev - 1) && nl <= dense_max;
-      if (!dense_last) {
-         // column blocks of this level's operator
-         V.B.n = nl;
-         V.B.nblk = ncol;
-         if (!upload (&V.B.blk_start, pblk.data (), pblk.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
-         int *dint = nullptr;
-         size_t dummy = 0;
-         std::vector<int> zeros (8, 0);
-         auto t_fac0 = clk::now ();
-         if (!upload (&dint, zeros.data (), 8, &dummy)) ML_FAIL (-2, "multilevel setup: device allocation failed");
-         launch_colblock_measure (V.L, V.B, dint, st);
-         int meas[3];
-         (void) hipMemcpyAsync (meas, dint, sizeof meas, hipMemcpyDeviceToHost, st);
-         (void) hipStreamSynchronize (st);
-         if (meas[1] > 0) { (void) hipFree (dint); ML_FAIL (-4, "multilevel setup: level %d has %d rows without a diagonal entry", l, meas[1]); }
-         V.B.max_len = meas[2];
-         V.B.P = meas[0] <= 1 ? 1 : meas[0] <= 2 ? 2 : 4;
-         if (!upload (&V.B.fac, (const double *) nullptr, (size_t) (2 * V.B.P + 1) * (size_t) nl, &H.device_bytes)) { (void) hipFree (dint); ML_FAIL (-2, "multilevel setup: device allocation failed"); }
-         (void) hipMemsetAsync (dint, 0, 8 * sizeof (int), st);
-         launch_colblock_factor (V.L, V.B, dint, st);
-         int st2[2];
-         (void) hipMemcpyAsync (st2, dint, sizeof st2, hipMemcpyDeviceToHost, st);
-         (void) hipStreamSynchronize (st);
-         (void) hipFree (dint);
-         if (st2[0] != 0) ML_FAIL (-4, "multilevel setup: zero pivot in a column block of level %d (row %d)", l, st2[0] - 1);
-         V.B.dropped = st2[1];
-         t_fac += secs (t_fac0);
-         {
-            auto t_lay0 = clk::now ();
-            const int ranges[3] = { 0, N.ncol0, ncol };
-            const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st, H.f32, H.fused ? prow.data () : nullptr);
-            if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
-            static int wave_max = -1;
-            if (wave_max < 0) { const char *e = getenv ("NKP_COLWAVE_MAX"); wave_max = e ? atoi (e) : 8192; }
-            V.wave_columns = ncol <= wave_max && V.B.dropped == 0;
-            t_lay += secs (t_lay0);
-         }
-         // f32 storage mode: the f64 copy of the level operator was only needed to factor the column blocks
-         if (V.L.valf && V.L.val) {
-            (void) hipStreamSynchronize (st);
-            (void) hipFree (V.L.val);
-            V.L.val = nullptr;
-            H.device_bytes -= ((size_t) prow[nl] + 2) * sizeof (double);
-         }
-      }
-      if (l < nlev - 1) {
-         // transfer operators in permuted orders
-         auto t_map0 = clk::now ();
-         Nat &C = nat[l + 1];
-         const int64_t nc = C.L.n;
-         V.nc = nc;
-         std::vector<int> cmap_p (nl);
-         for (int64_t i = 0; i < nl; i++) cmap_p[i] = C.inv[N.cmap[N.perm[i]]];
-         std::vector<int> rptr (nc + 1, 0), ridx (nl);
-         for (int64_t i = 0; i < nl; i++) rptr[cmap_p[i] + 1]++;
-         for (int64_t I = 0; I < nc; I++) rptr[I + 1] += rptr[I];
-         {
-            std::vector<int> fill (rptr.begin (), rptr.end () - 1);
-            for (int64_t i = 0; i < nl; i++) ridx[fill[cmap_p[i]]++] = (int) i;
-         }
-         if (!(upload (&V.cmap, cmap_p.data (), (size_t) nl, &H.device_bytes) && upload (&V.rptr, rptr.data (), (size_t) nc + 1, &H.device_bytes) &&
-               upload (&V.ridx, ridx.data (), (size_t) nl, &H.device_bytes)))
-            ML_FAIL (-2, "multilevel setup: device allocation failed");
-         t_map += secs (t_map0);
-      }
-      if (dense_last) {
-         // coarsest level: dense inverse (permuted order)
-         std::vector<double> dense ((size_t) nl * nl, 0.0);
-         for (int64_t i = 0; i < nl; i++)
-            for (int e = prow[i]; e < prow[i + 1]; e++) dense[(size_t) i * nl + pcol[e]] = pval[e];
-         static int host_inverse = -1;
-         if (host_inverse < 0) { const char *e = getenv ("NKP_ML_HOST_INVERSE"); host_inverse = e ? atoi (e) != 0 : 0; }
-         if (host_inverse) {
-            if (!dense_inverse ((int) nl, dense)) ML_FAIL (-4, "multilevel setup: coarsest operator is singular");
-            if (!upload (&H.coarse_inv, dense.data (), dense.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
-         } else if (!dense_inverse_device ((int) nl, dense, &H.coarse_inv, &H.device_bytes, st))
-            ML_FAIL (-4, "multilevel setup: coarsest operator is singular (or the device is out of memory)");
-      }
-      if (verbose)
-         printf ("(%d) multilevel: level %d: %lld rows, %lld entries, %d columns (%d + %d by colour)%s\n", rank, l, (long long) nl,
-                 (long long) prow[nl], ncol, N.ncol0, ncol - N.ncol0, l < nlev - 1 ? "" : dense_last ? ", dense solve" : ", relaxed (too large for a dense inverse)");
-      t_dev += secs (t_dev0);
+   // ---- host-built levels in colour-major order
+   const int nlev = l0 + (int) hnat.size ();
+   H.lev.resize (nlev);
+   for (int l = l0; l < nlev; l++) {
+      const int frc = finalize_host_level (H, l, nlev, hnat[(size_t) (l - l0)], l + 1 < nlev ? &hnat[(size_t) (l - l0 + 1)] : nullptr, verbose, rank, st, err, errlen, T);
+      if (frc) return frc;
    }
    {
       // the small end of the cycle in one single-workgroup launch: the last levels whose rows add up to <= NKP_ML_TAIL_ROWS
@@ -1133,16 +1450,18 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
       }
       if (verbose && H.tail_from >= 0) printf ("(%d) multilevel: levels %d..%d run as one single-workgroup launch\n", rank, H.tail_from, nlev - 1);
    }
+   H.setup_seconds = secs_since (t_begin);
+   H.levels_on_device = ndev_levels;
    if (verbose) {
-      printf ("(%d) multilevel setup: %.2f s low-order twin, %.2f s column graphs, %.2f s Galerkin products, %.2f s colour-major permutation, "
-              "%.2f s uploads + factorisation + lane layouts (row blocks %.2f, operator uploads %.2f, column factors %.2f, lane layouts %.2f, transfer maps %.2f); "
-              "host part as a whole %.2f s, everything %.2f s\n",
-              rank, t_low, t_graph, t_galerkin, t_perm, t_dev, t_rb, t_up, t_fac, t_lay, t_map, t_host, secs (t_begin));
+      printf ("(%d) multilevel setup: %d of %d levels built on the device (%.3f s twin, %.3f s coarse cells, %.3f s Galerkin products); host levels: %.3f s twin, %.3f s "
+              "column graphs + coarse cells, %.3f s Galerkin products; colour-major operators %.3f s, row blocks %.3f, uploads + f32 copies %.3f, column factors %.3f, "
+              "lane layouts %.3f, transfer maps %.3f; hierarchy construction as a whole %.3f s, everything %.3f s\n",
+              rank, ndev_levels, nlev, T.twin, T.agg, T.galerkin, TH.low, TH.graph, TH.galerkin, T.perm, T.rb, T.up, T.fac, T.lay, T.map, t_plan, H.setup_seconds);
       fflush (stdout);
    }
    return 0;
-#undef ML_FAIL
 }
+#undef ML_FAIL
 
 void ml_free (MlHierarchy &H)
 {

@@ -6,6 +6,8 @@
 #define NKP_LDSRES_CH 16         // substitution steps per factor chunk of colblock_apply_ldsres_kernel (group lengths are padded to it)
 #define NKP_WAVE 64
 #define NKP_MAX_K 512           // most basis vectors a fused update kernel takes (LDS coefficients)
+#define NKP_SPMV_LDS_NNZ 2048    // CSR-stream row block: entries staged in LDS ...
+#define NKP_SPMV_MAX_ROWS 256    // ... and rows (= threads of the SpMV workgroup) at most
 
 // ---------------------------------------------------------------- CSR matrix on the device
 struct CsrDev {

@@ -127,6 +127,7 @@ struct nkp_solver {
    double *hpin = nullptr;          // pinned host mirror
    int *dint = nullptr;             // device ints
    size_t device_bytes = 0;
+   double create_seconds = 0.0;     // wall time of nkp_create
    double *h_dev () { return dscal; }
    double *h2_dev () { return dscal + (m + 2); }
    double *misc_dev () { return dscal + 2 * (m + 2); }     // [0]=nrm2 [1]=inv [2]=dot out ...
@@ -504,7 +505,9 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
       const int mrc = pm ? ml_setup (s->ml, pm->n, pm->rowptr, pm->colind, pm->val, pm->blk_start, pm->nblk, pm->col_i, pm->col_j, pm->col_t, coupled_tracer_cnt, opt.ml_levels,
                                      opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err)
                          : ml_setup (s->ml, n, rowptr, colind, val, blk_start, nblk, blk_default.empty () ? opt.col_i : nullptr, blk_default.empty () ? opt.col_j : nullptr, blk_default.empty () ? opt.col_t : nullptr,
-                                     coupled_tracer_cnt, opt.ml_levels, opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err);
+                                     coupled_tracer_cnt, opt.ml_levels, opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err,
+                                     // the SpMV's device copy is this very matrix unless the columns were renumbered (distributed flavour) or filtered
+                                     (!spmv_mat && f_rowptr.empty ()) ? &s->A : nullptr);
       if (mrc != 0) {
          rc = fail (mrc, "nkp_create: %s", err);
          solver_free (s);
@@ -559,10 +562,40 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    TRYHIP (hipGetLastError ());
    msg (s, 1, "nkp_create: n = %lld, nnz = %lld, %d SpMV row blocks, %.1f MB on device %d; %.2f s matrix upload + row blocks, %.2f s work vectors, %.2f s preconditioner\n",
         (long long) n, (long long) M.nnz, s->A.nrowblk, (double) s->device_bytes / 1.0e6, s->device, t_matrix, t_work - t_matrix, since0 () - t_work);
+   s->create_seconds = since0 ();
    *out = s;
    return NKP_OK;
 #undef TRY
 #undef TRYHIP
+}
+
+// ---------------------------------------------------------------- hierarchy introspection (tests)
+extern "C" int64_t nkp_ml_level_array (nkp_solver *s, int level, const char *what, void *dst, int64_t capacity_bytes)
+{
+   if (!s || !what || s->opt.precond != NKP_PRECOND_MULTILEVEL || level < 0 || level >= (int) s->ml.lev.size ()) return fail (NKP_EINVAL, "nkp_ml_level_array: bad argument");
+   const MlLevel &V = s->ml.lev[(size_t) level];
+   const bool last = level == (int) s->ml.lev.size () - 1;
+   const void *src = nullptr;
+   int64_t count = 0;
+   size_t elem = 4;
+   if (!strcmp (what, "rowptr")) { src = V.L.rowptr; count = V.n + 1; }
+   else if (!strcmp (what, "colind")) { src = V.L.colind; count = V.L.nnz; }
+   else if (!strcmp (what, "valf")) { src = V.L.valf; count = V.L.valf ? V.L.nnz : 0; }
+   else if (!strcmp (what, "val")) { src = V.L.val; count = V.L.val ? V.L.nnz : 0; elem = 8; }
+   else if (!strcmp (what, "cmap")) { src = V.cmap; count = V.cmap ? V.n : 0; }
+   else if (!strcmp (what, "rptr")) { src = V.rptr; count = V.rptr ? V.nc + 1 : 0; }
+   else if (!strcmp (what, "ridx")) { src = V.ridx; count = V.ridx ? V.n : 0; }
+   else if (!strcmp (what, "blk_start")) { src = V.B.blk_start; count = V.B.blk_start ? V.B.nblk + 1 : 0; }
+   else if (!strcmp (what, "fac")) { src = V.B.fac; count = V.B.fac ? (int64_t) (2 * V.B.P + 1) * V.n : 0; elem = 8; }
+   else if (!strcmp (what, "perm0")) { src = level == 0 ? s->ml.perm0 : nullptr; count = src ? V.n : 0; }
+   else if (!strcmp (what, "coarse_inv")) { src = last ? s->ml.coarse_inv : nullptr; count = src ? V.n * V.n : 0; elem = 8; }
+   else return fail (NKP_EINVAL, "nkp_ml_level_array: unknown array '%s'", what);
+   if (!dst) return count;
+   if (count * (int64_t) elem > capacity_bytes) return fail (NKP_EINVAL, "nkp_ml_level_array: buffer too small");
+   HIPCHK (hipSetDevice (s->device));
+   HIPCHK (hipStreamSynchronize (s->stream));
+   if (count) HIPCHK (hipMemcpy (dst, src, (size_t) count * elem, hipMemcpyDeviceToHost));
+   return count;
 }
 
 extern "C" int nkp_create (nkp_solver **out, const nkp_options *opt, int64_t n, int64_t nnz,
@@ -624,6 +657,9 @@ extern "C" int64_t nkp_get_int (nkp_solver *s, const char *key)
    if (!strcmp (key, "smoother_spmv_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 0) : 0;
    if (!strcmp (key, "column_solve_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 1) : 0;
    if (!strcmp (key, "cycle_bytes")) return s->opt.precond == NKP_PRECOND_MULTILEVEL ? ml_bytes (s->ml, 2) : 0;
+   if (!strcmp (key, "ml_levels_on_device")) return s->ml.levels_on_device;
+   if (!strcmp (key, "ml_setup_us")) return (int64_t) (s->ml.setup_seconds * 1.0e6);
+   if (!strcmp (key, "create_us")) return (int64_t) (s->create_seconds * 1.0e6);
    return -1;
 }
 

@@ -16,8 +16,8 @@
 #include <stdlib.h>
 
 #define SPMV_THREADS 256
-#define SPMV_LDS_NNZ 2048
-#define SPMV_MAX_ROWS 256
+#define SPMV_LDS_NNZ NKP_SPMV_LDS_NNZ
+#define SPMV_MAX_ROWS NKP_SPMV_MAX_ROWS
 
 template <int MODE, int VAR, class VT>   // MODE 0: y = A x   1: y = b - A x   2: y = |A||x| + |b| ; VAR: load flavour ; VT: stored value type
 __global__ __launch_bounds__ (SPMV_THREADS)

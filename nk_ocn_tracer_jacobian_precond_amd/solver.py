@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host", "nkp_set_device",
     "nkp_gather_root", "nkp_clone", "nkp_ml_plan_host", "nkp_comm_file_init", "nkp_comm_file_free",
     "nkp_create64", "nkp_cell_major_order", "nkp_permuted_rows", "nkp_dist_overlap_plan_host", "nkp_dist_plan_size",
-    "nkp_dist_plan_copy", "nkp_dist_plan_free",
+    "nkp_dist_plan_copy", "nkp_dist_plan_free", "nkp_ml_level_array",
 ]
 
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
@@ -87,6 +87,8 @@ def load_library(path=None):
     lib.nkp_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f64p]
     lib.nkp_get_int.argtypes = [vp, C.c_char_p]
     lib.nkp_get_int.restype = C.c_int64
+    lib.nkp_ml_level_array.argtypes = [vp, C.c_int, C.c_char_p, vp, C.c_int64]
+    lib.nkp_ml_level_array.restype = C.c_int64
     lib.nkp_set_stream.argtypes = [vp, vp]
     lib.nkp_destroy.argtypes = [vp]
     lib.nkp_destroy.restype = None
@@ -298,6 +300,20 @@ class NkpSolver:
 
     def get_int(self, key):
         return int(self._lib.nkp_get_int(self._h, key.encode()))
+
+    _ML_ARRAY_TYPES = {"valf": np.float32, "val": np.float64, "fac": np.float64, "coarse_inv": np.float64}
+
+    def ml_level_array(self, level, what):
+        """One array of the multilevel hierarchy as it sits on the device (nkp_ml_level_array); empty if the level has none."""
+        cnt = int(self._lib.nkp_ml_level_array(self._h, level, what.encode(), None, 0))
+        if cnt < 0:
+            raise NkpError(cnt, last_error())
+        out = np.empty(cnt, self._ML_ARRAY_TYPES.get(what, np.int32))
+        if cnt:
+            got = int(self._lib.nkp_ml_level_array(self._h, level, what.encode(), out.ctypes.data_as(C.c_void_p), out.nbytes))
+            if got != cnt:
+                raise NkpError(got, last_error())
+        return out
 
     def set_stream(self, stream_ptr):
         self._check(self._lib.nkp_set_stream(self._h, C.c_void_p(stream_ptr)))
