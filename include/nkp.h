@@ -65,6 +65,64 @@ enum {
    NKP_ECOMM = -5
 };
 
+/* Tuning knobs of the solve path (all optional).  The defaults are the measured best (DESIGN.md sections 2, 4, 11); everything
+ * else exists for A/B runs and tests.  A solver reads them ONCE, in nkp_create: from nkp_options.tuning when the caller sets
+ * it, else from nkp_default_tuning, which starts from the defaults and applies the NKP_* environment variables named on the
+ * right (how the reference-shaped executables, which have no room for options, are steered).  They are per solver: nothing in
+ * a solve, a cycle or a kernel launch looks at the environment. */
+typedef struct nkp_tuning {
+   int struct_size;          /* = sizeof(nkp_tuning), ABI guard */
+   /* ---- hierarchy construction */
+   int ml_split;             /* NKP_ML_SPLIT (1): connectivity-aware coarse cells inside the geometric groups */
+   int ml_pocket;            /* NKP_ML_POCKET (4): same-depth connected sets of at most that many cells become one coarse cell */
+   int ml_big_from;          /* NKP_ML_BIG_FROM (-3 = automatic): 4 x 4 groups from that level on, -1 = never */
+   int ml_coarsest_rows;     /* NKP_ML_COARSEST_ROWS (3000): stop coarsening at that many rows */
+   int ml_dense_max;         /* NKP_ML_DENSE_MAX (6000): largest last level solved with a dense inverse */
+   double ml_theta;          /* NKP_ML_THETA (0): edge threshold of the connectivity test */
+   double ml_tau;            /* NKP_ML_TAU (0.01): leaf-stub threshold */
+   int64_t ml_device_min;    /* NKP_ML_DEVICE_MIN (100000): levels with at least that many rows are built by the setup kernels,
+                                smaller ones on the host (same hierarchy either way); < 0 = host only */
+   /* ---- cycle */
+   int ml_smooth_coarse;     /* NKP_ML_SMOOTH_COARSE (0 = like the fine levels): sweeps on levels >= ml_coarse_from */
+   int ml_coarse_from;       /* NKP_ML_COARSE_FROM (2) */
+   int ml_gamma_from, ml_gamma_to;   /* NKP_ML_GAMMA_FROM / _TO (0, 0): levels [from, to) visit the coarse level twice */
+   int ml_f32;               /* NKP_ML_F32 (1): level operators and column factors stored in f32 (arithmetic in f64) */
+   int ml_host_inverse;      /* NKP_ML_HOST_INVERSE (0): dense inverse of the last level on the host */
+   int ml_fused;             /* NKP_ML_FUSED (0): one launch per Gauss-Seidel half sweep */
+   int ml_fused_max_cols;    /* NKP_ML_FUSED_MAX_COLS (0 = all): ... only on levels with at most that many columns */
+   int ml_coarsest_sweeps;   /* NKP_ML_COARSEST_SWEEPS (30): sweeps on a last level too large for a dense inverse */
+   int64_t ml_tail_rows;     /* NKP_ML_TAIL_ROWS (0): the last levels with at most that many rows in one launch */
+   double ml_omega;          /* NKP_ML_OMEGA (1.1): weight of the coarse-grid correction */
+   /* ---- water-column solves: which kernel serves which level */
+   int col_ldsres;           /* NKP_COL_LDSRES (2) */
+   int col_stream;           /* NKP_COLSTREAM (1) */
+   int col_stream_min;       /* NKP_COLSTREAM_MIN (-1 = per-kernel defaults) */
+   int col_stream_gw;        /* NKP_COLSTREAM_GW (32) */
+   int col_wave_max;         /* NKP_COLWAVE_MAX (8192): levels with at most that many columns solve one column per wave */
+   int col_w3;               /* NKP_COL_W3 (1) */
+   int col_group;            /* NKP_COLGROUP (8) */
+   int col_pipe_min;         /* NKP_COLPIPE_MIN (0 = off) */
+   int col_ldsres_early;     /* NKP_LDSRES_EARLY (0) */
+   /* ---- CSR SpMV launch shape */
+   int spmv_variant;         /* NKP_SPMV_VARIANT (4) */
+   int spmv_compress;        /* NKP_SPMV_COMPRESS (0): 2-byte column codes */
+   int spmv_pipe_min;        /* NKP_SPMV_PIPE_MIN (1024): fewest row blocks for the pipelined kernel */
+   int spmv_run;             /* NKP_SPMV_RUN (1): row blocks one workgroup walks */
+   int spmv_wgs;             /* NKP_SPMV_WGS (256): workgroups per CU at most */
+   /* ---- Krylov / distributed flavour / setup */
+   int precond_steps;        /* NKP_PRECOND_STEPS (0 = leave nkp_options.precond_steps) */
+   int equil;                /* NKP_EQUIL (-1 = leave nkp_options.equil) */
+   int dist_overlap;         /* NKP_DIST_OVERLAP (1): halo exchange behind the interior rows */
+   int dist_ras;             /* NKP_DIST_RAS (1): one ring of the neighbours' columns in the rank's hierarchy */
+   int force_dist;           /* NKP_FORCE_DIST (0): distributed code path with one rank */
+   int setup_threads;        /* NKP_SETUP_THREADS (0 = automatic): host threads of the setup loops */
+   int plan_times;           /* NKP_ML_PLAN_TIMES (0): print the split of the host-side aggregation */
+   int ml_drop_intertracer;  /* NKP_ML_DROP_INTERTRACER (0): developer switch, hierarchy without inter-tracer couplings */
+} nkp_tuning;
+
+/* defaults, then the NKP_* environment overrides listed above */
+int nkp_default_tuning (nkp_tuning *t);
+
 typedef struct nkp_options {
    int struct_size;      /* = sizeof(nkp_options), ABI guard                                  */
    int precond;          /* enum nkp_precond                                                  */
@@ -100,6 +158,8 @@ typedef struct nkp_options {
     * src/matrix.c:778-784): block c belongs to tracer c / (nblk / coupled_tracer_cnt).  Needed when the rows were
     * reordered cell-major (nkp_cell_major_order below).  Columns of different tracers are never aggregated together. */
    const int32_t *col_t;
+   /* optional: tuning knobs (NULL = nkp_default_tuning: defaults + NKP_* environment).  Read during nkp_create only. */
+   const nkp_tuning *tuning;
 } nkp_options;
 
 int nkp_default_options (nkp_options *opt);

@@ -811,20 +811,19 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    bool gs_ok = h_rowptr != nullptr;
    std::vector<long long> base;
    // columns per wave: the group's factors + right-hand side must fit LDS several times per CU
-   int gw = 8;
-   if (const char *e = getenv ("NKP_COLGROUP")) gw = atoi (e);
+   const nkp_tuning &T = B.tune ? *B.tune : nkp_builtin_tuning ();
+   int gw = T.col_group;
    if (gw != 8 && gw != 16 && gw != 32 && gw != 64) gw = 8;
    // levels with many columns: 32 or 64 columns per wave, factors streamed from HBM instead of staged in LDS
-   // (colblock_apply_stream_kernel); NKP_COLSTREAM=0 disables, NKP_COLSTREAM_MIN = fewest columns of a level that uses it
+   // (colblock_apply_stream_kernel); col_stream = 0 disables, col_stream_min = fewest columns of a level that uses it
    {
       // measured at 1 degree (93 MB per colour of the fine level): 8 columns per wave with LDS-staged factors 44.7 us,
       // 64 streamed 33.6 us, 32 streamed 26.2 us (3.55 TB/s); on levels below ~50 000 columns the fewer, longer waves of
       // the streamed kernel lose to the small-group kernel (whole cycle 2.69 -> 2.52 ms with the fine level only, 2.55 with
       // the first two levels, 2.61 with three)
-      int on = 1, min_cols = 50000, sgw = 32;
-      if (const char *e = getenv ("NKP_COLSTREAM")) on = atoi (e) != 0;
-      if (const char *e = getenv ("NKP_COLSTREAM_MIN")) min_cols = atoi (e);
-      if (const char *e = getenv ("NKP_COLSTREAM_GW")) sgw = atoi (e) == 64 ? 64 : 32;
+      const int on = T.col_stream != 0, sgw = T.col_stream_gw == 64 ? 64 : 32;
+      const bool env_min = T.col_stream_min >= 0;
+      const int min_cols = env_min ? T.col_stream_min : 50000;
       // the column lives in registers: beyond 64 levels the kernel needs all 256 VGPRs (one wave per SIMD) and loses --
       // 0.25 degree x 80 levels: cycle 46.2 ms with it against 32.8 ms with the small-group kernel
       B.stream = on && ranges[nranges] - ranges[0] >= min_cols && B.max_len <= 64;
@@ -834,10 +833,8 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       // LDS-resident on levels 0 and 1: 2.385 / 2.394 ms; streamed on level 0, small groups on level 1: 2.410 / 2.427;
       // streamed on level 0, LDS-resident on level 1: 2.434 / 2.409.  NKP_COL_LDSRES=1 keeps it to the long columns (and
       // the streamed kernel on the largest levels), =0 switches it off.
-      int lr = 2;
-      if (const char *e = getenv ("NKP_COL_LDSRES")) lr = atoi (e);
+      const int lr = T.col_ldsres;
       const int ncols = ranges[nranges] - ranges[0];
-      const bool env_min = getenv ("NKP_COLSTREAM_MIN") != nullptr;
       const int min_long = env_min ? min_cols : 8000, min_short = env_min ? min_cols : 20000;
       B.ldsres = lr > 0 && on && B.max_len <= 128 && ((B.max_len > 64 && ncols >= min_long) || (lr == 2 && ncols >= min_short));
       if (B.ldsres) { B.stream = 0; gw = 32; }
@@ -1255,8 +1252,7 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
       // NKP_COLPIPE_MIN=<groups> is set: it needs 256 VGPRs (one wave per SIMD), and with nothing to interleave the
       // recurrence's own dependency stalls cost more than the hidden load latency saves -- 1 degree V-cycle 3.10 ms
       // against 2.70 ms for the one-group-per-wave kernel (bit-identical results)
-      static int pipe_min = -1;
-      if (pipe_min < 0) { const char *e = getenv ("NKP_COLPIPE_MIN"); pipe_min = e ? atoi (e) : 0; }
+      const int pipe_min = B.tune ? B.tune->col_pipe_min : 0;
       if (B.fac_tf && B.max_len <= 64 && B.gw == 8 && B.P <= 2 && pipe_min > 0 && g1 - g0 >= pipe_min && lds <= 48 * 1024) {
          int waves = 256 * 8;                         // two waves per SIMD fit the ~230 registers
          if (waves > (g1 - g0 + 1) / 2) waves = (g1 - g0 + 1) / 2;
@@ -1275,11 +1271,10 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
          else hipLaunchKernelGGL ((colblock_apply_ldsres_kernel<PP, double, NKP_LDSRES_CH, EE>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.grp_nb, B.grp_maxlen,         \
                                   B.grp_base, g0, B.fac_t, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp);                                                    \
       } while (0)
-      static int early = -1;
-      // NKP_LDSRES_EARLY=1: first factor chunks and the accumulate target requested before the right-hand side is staged
+      // col_ldsres_early = 1: first factor chunks and the accumulate target requested before the right-hand side is staged
       // (247 instead of 172 VGPRs).  Measured twice on one box: 26.9 / 26.6 us per colour of the 1 degree fine level with it,
       // 26.8 / 27.0 without -- no difference, so it stays off
-      if (early < 0) { const char *e = getenv ("NKP_LDSRES_EARLY"); early = e ? atoi (e) != 0 : 0; }
+      const int early = B.tune ? B.tune->col_ldsres_early : 0;
 #define LDSRES_LAUNCH(PP) do { if (early) LDSRES_LAUNCH2 (PP, true); else LDSRES_LAUNCH2 (PP, false); } while (0)
       if (B.P == 1) LDSRES_LAUNCH (1);
       else if (B.P == 2) LDSRES_LAUNCH (2);
@@ -1306,8 +1301,7 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
 #undef STREAM_LAUNCH3
       return;
    }
-   static int use_w3 = -1;
-   if (use_w3 < 0) { const char *e = getenv ("NKP_COL_W3"); use_w3 = e ? atoi (e) != 0 : 1; }
+   const int use_w3 = B.tune ? B.tune->col_w3 : 1;
 #define LANES_LAUNCH_W3(PP, ML)                                                                                                                                 \
    do {                                                                                                                                                        \
       if (B.fac_tf) hipLaunchKernelGGL ((colblock_apply_lanes_kernel_w3<PP, ML, float>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.blk_start, B.grp_b0, B.grp_nb, \

@@ -180,9 +180,38 @@ extern "C" void nkp_comm_file_free (nkp_comm_ops *ops)
 {
    if (!ops || !ops->ctx) return;
    FileCtx *c = (FileCtx *) ops->ctx;
-   // the last two collectives' files are still there: nobody reads them any more once every rank has left its last
-   // collective, which is the case when the caller tears down after a final synchronising call
-   for (long q = c->seq >= 2 ? c->seq - 2 : 0; q < c->seq; q++) (void) unlink (path_of (c, q, c->rank).c_str ());
+   // Teardown without a race: a rank that has left its last collective may be far ahead of a peer that is still reading
+   // this rank's file of that collective (nkp_gather_root: rank 0 fetches everybody's slice last).  So every rank first
+   // takes part in one more allgather -- a peer that has WRITTEN its file of it has finished reading everything before --
+   // and removes its older files; the files of that last allgather stay until every rank > 0 has dropped a "done" token
+   // (written after its last read), then rank 0 removes them all.  A peer that died shows as a missed deadline: its files
+   // are left behind rather than waited for.
+   std::vector<int64_t> all ((size_t) c->nranks + 1, 0);
+   const long last = c->seq;
+   const bool joined = file_allgather_i64_host (c, 0, all.data ()) == 0;
+   for (long q = last >= 2 ? last - 2 : 0; q < last; q++) (void) unlink (path_of (c, q, c->rank).c_str ());
+   if (joined) {
+      const std::string done = c->dir + "/done.";
+      if (c->rank != 0) {
+         FILE *f = fopen ((done + std::to_string (c->rank)).c_str (), "wb");
+         if (f) fclose (f);
+      } else {
+         const double deadline = now () + c->timeout;
+         bool everyone = true;
+         for (int p = 1; p < c->nranks && everyone; p++) {
+            const std::string fn = done + std::to_string (p);
+            while (access (fn.c_str (), F_OK) != 0) {
+               if (now () > deadline) { everyone = false; break; }
+               usleep (200);
+            }
+         }
+         if (everyone)
+            for (int p = 0; p < c->nranks; p++) {
+               (void) unlink (path_of (c, last, p).c_str ());
+               if (p) (void) unlink ((done + std::to_string (p)).c_str ());
+            }
+      }
+   }
    delete c;
    ops->ctx = nullptr;
 }

@@ -17,6 +17,7 @@ struct RcclCtx {
    int rank = 0, nranks = 1;
    void *stage = nullptr;
    size_t stage_bytes = 0;
+   bool failed = false;          // a call on this communicator failed: it is aborted at teardown, not destroyed
 };
 
 int ensure_stage (RcclCtx *c, size_t bytes)
@@ -33,7 +34,9 @@ int ensure_stage (RcclCtx *c, size_t bytes)
 int rccl_allreduce (void *ctx, void *dev_buf, int count, int op, void *stream)
 {
    RcclCtx *c = (RcclCtx *) ctx;
-   return ncclAllReduce (dev_buf, dev_buf, (size_t) count, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, (hipStream_t) stream) != ncclSuccess;
+   const bool bad = ncclAllReduce (dev_buf, dev_buf, (size_t) count, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, (hipStream_t) stream) != ncclSuccess;
+   if (bad) c->failed = true;
+   return bad;
 }
 
 template <class T>
@@ -52,6 +55,7 @@ int exchange (RcclCtx *c, const T *send, const int *scnt, T *recv, const int *rc
       ro += (size_t) rcnt[p];
    }
    ncclResult_t e = ncclGroupEnd ();
+   if (r != ncclSuccess || e != ncclSuccess) c->failed = true;
    return (r != ncclSuccess || e != ncclSuccess);
 }
 
@@ -80,7 +84,7 @@ int rccl_allgather_i64_host (void *ctx, int64_t mine, int64_t *all)
    if (ensure_stage (c, ((size_t) c->nranks + 1) * sizeof (int64_t))) return 1;
    int64_t *d = (int64_t *) c->stage;
    if (hipMemcpy (d + c->nranks, &mine, sizeof mine, hipMemcpyHostToDevice) != hipSuccess) return 1;
-   if (ncclAllGather (d + c->nranks, d, 1, ncclInt64, c->comm, (hipStream_t) 0) != ncclSuccess) return 1;
+   if (ncclAllGather (d + c->nranks, d, 1, ncclInt64, c->comm, (hipStream_t) 0) != ncclSuccess) { c->failed = true; return 1; }
    if (hipStreamSynchronize (0) != hipSuccess) return 1;
    return hipMemcpy (all, d, (size_t) c->nranks * sizeof (int64_t), hipMemcpyDeviceToHost) != hipSuccess;
 }
@@ -120,7 +124,14 @@ extern "C" void nkp_comm_rccl_free (nkp_comm_ops *ops)
    if (!ops || !ops->ctx) return;
    RcclCtx *c = (RcclCtx *) ops->ctx;
    if (c->stage) (void) hipFree (c->stage);
-   if (c->comm) (void) ncclCommDestroy (c->comm);
+   if (c->comm) {
+      // ncclCommDestroy waits for the communicator's outstanding operations; after a failure (or an asynchronous error RCCL
+      // has recorded) there may be one that never completes, and the peers must see this rank go away instead of waiting
+      ncclResult_t async = ncclSuccess;
+      if (ncclCommGetAsyncError (c->comm, &async) != ncclSuccess || async != ncclSuccess) c->failed = true;
+      if (c->failed) (void) ncclCommAbort (c->comm);
+      else (void) ncclCommDestroy (c->comm);
+   }
    delete c;
    ops->ctx = nullptr;
 }

@@ -36,7 +36,8 @@ struct MlHierarchy {
    int fused = 1;               // one launch per Gauss-Seidel half sweep (gs_fused_kernel) where the level allows it
    int tail_from = -1;          // levels >= tail_from run in ONE single-workgroup launch (mltail.hip); -1 = none
    int gamma_from = 0, gamma_to = 0;   // levels [from, to) apply the coarse-grid correction twice (W-cycle there)
-   double omega = 0.0;          // scaling of the coarse-grid correction (0 = not read yet; NKP_ML_OMEGA, default 1)
+   double omega = 1.1;          // weight of the coarse-grid correction
+   const nkp_tuning *tune = nullptr;   // the owning solver's knobs (set by ml_setup)
    size_t device_bytes = 0;
    double setup_seconds = 0.0;  // wall time of ml_setup
    int levels_on_device = 0;    // levels whose operator was built by the kernels of mlsetup.hip
@@ -46,7 +47,7 @@ struct MlHierarchy {
 int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, const double *val,
               const int *blk_start, int64_t nblk, const int *col_i, const int *col_j, const int *col_t /* tracer of every column, or NULL = positional */,
               int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
-              hipStream_t st, char *err, size_t errlen, const CsrDev *A_dev = nullptr /* device copy of the same matrix, if the caller has one */);
+              hipStream_t st, char *err, size_t errlen, const nkp_tuning &tune, const CsrDev *A_dev = nullptr /* device copy of the same matrix, if the caller has one */);
 void ml_free (MlHierarchy &H);
 // z = V-cycle(r) in the ORIGINAL row order
 void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st);

@@ -66,18 +66,19 @@ struct HostCsr {
 };
 
 // ---------------------------------------------------------------- host threads for the setup loops
-int setup_threads ()
+// host threads of the setup loops and the timing print of the aggregation: set at the start of every setup call from the
+// solver's tuning (1 degree, 256-core host: Galerkin products 0.25 / 0.14 / 0.11 s with 16 / 32 / 64 threads; 32 leaves room
+// for one process per GPU on an 8-GPU node)
+thread_local int g_setup_threads = 0;
+thread_local bool g_plan_times = false;
+
+void use_setup_knobs (const nkp_tuning &t)
 {
-   static int t = -1;
-   if (t < 0) {
-      const char *e = getenv ("NKP_SETUP_THREADS");
-      // 1 degree, 256-core host: Galerkin products 0.25 / 0.14 / 0.11 s with 16 / 32 / 64 threads; 32 leaves room for one
-      // process per GPU on an 8-GPU node
-      t = e ? atoi (e) : (int) std::min (32u, std::max (1u, std::thread::hardware_concurrency ()));
-      if (t < 1) t = 1;
-   }
-   return t;
+   g_setup_threads = t.setup_threads > 0 ? t.setup_threads : (int) std::min (32u, std::max (1u, std::thread::hardware_concurrency ()));
+   g_plan_times = t.plan_times != 0;
 }
+
+int setup_threads () { return g_setup_threads > 0 ? g_setup_threads : 1; }
 
 // run fn (chunk, first_row, last_row) on contiguous row chunks, one host thread each
 template <class F>
@@ -305,7 +306,7 @@ void split_aggregate (const HostCsr &L, const std::vector<int> &blk_start, const
 {
    const int64_t n = L.n;
    const int ncol = (int) blk_start.size () - 1;
-   const bool timing = getenv ("NKP_ML_PLAN_TIMES") != nullptr;
+   const bool timing = g_plan_times;
    auto tick0 = std::chrono::steady_clock::now ();
    auto lap = [&] (const char *what) {
       if (!timing) return;
@@ -732,21 +733,20 @@ struct Nat {
 
 struct SetupTimes { double low = 0.0, graph = 0.0, galerkin = 0.0; };
 
-// knobs of the hierarchy construction, read once per setup (environment; defaults are the measured best)
+// knobs of the hierarchy construction (nkp_tuning; defaults are the measured best)
 struct PlanKnobs {
    int split = 1, pocket = 4, big_from = -3;
    double theta = 0.0, tau = 0.01;
 };
 
-PlanKnobs read_plan_knobs ()
+PlanKnobs plan_knobs (const nkp_tuning &t)
 {
    PlanKnobs k;
-   const char *e;
-   if ((e = getenv ("NKP_ML_SPLIT"))) k.split = atoi (e) != 0;
-   if ((e = getenv ("NKP_ML_POCKET"))) k.pocket = atoi (e);
-   if ((e = getenv ("NKP_ML_THETA"))) k.theta = atof (e);
-   if ((e = getenv ("NKP_ML_TAU"))) k.tau = atof (e);
-   if ((e = getenv ("NKP_ML_BIG_FROM"))) k.big_from = atoi (e);
+   k.split = t.ml_split != 0;
+   k.pocket = t.ml_pocket;
+   k.theta = t.ml_theta;
+   k.tau = t.ml_tau;
+   k.big_from = t.ml_big_from;
    return k;
 }
 
@@ -941,10 +941,13 @@ extern "C" int nkp_ml_plan_host (int64_t n, const int32_t *rowptr, const int32_t
    if (max_levels <= 0) max_levels = 12;
    std::vector<Nat> nat (1);
    SetupTimes T;
-   const PlanKnobs K = read_plan_knobs ();
+   nkp_tuning tune;
+   nkp_default_tuning (&tune);                     // test entry point: defaults + environment
+   use_setup_knobs (tune);
+   const PlanKnobs K = plan_knobs (tune);
    init_first_nat (nat[0], n, rowptr, colind, val, blk_start, nblk, col_i, col_j, nullptr, coupled_tracer_cnt, true, T);
    extend_nat_levels (nat, 0, (int) nblk, coupled_tracer_cnt, max_levels, coarsest_rows, 0, 0, K, T);
-   if (getenv ("NKP_ML_PLAN_TIMES")) printf ("nkp_ml_plan_host: %.2f s low-order twin, %.2f s graphs + aggregation, %.2f s Galerkin products\n", T.low, T.graph, T.galerkin);
+   if (tune.plan_times) printf ("nkp_ml_plan_host: %.2f s low-order twin, %.2f s graphs + aggregation, %.2f s Galerkin products\n", T.low, T.graph, T.galerkin);
    *n_levels = (int) nat.size ();
    int64_t qc = 0, qo = 0;
    for (size_t l = 0; l < nat.size (); l++) {
@@ -979,6 +982,7 @@ int finish_level_columns (MlHierarchy &H, MlLevel &V, int l, const std::vector<i
    const int64_t nl = V.n;
    V.B.n = nl;
    V.B.nblk = ncol;
+   V.B.tune = H.tune;
    if (!upload (&V.B.blk_start, pblk.data (), pblk.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
    int *dint = nullptr;
    size_t dummy = 0;
@@ -1007,9 +1011,7 @@ int finish_level_columns (MlHierarchy &H, MlLevel &V, int l, const std::vector<i
       const int ranges[3] = { 0, ncol0, ncol };
       const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st, H.f32, H.fused ? h_prow : nullptr);
       if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
-      static int wave_max = -1;
-      if (wave_max < 0) { const char *e = getenv ("NKP_COLWAVE_MAX"); wave_max = e ? atoi (e) : 8192; }
-      V.wave_columns = ncol <= wave_max && V.B.dropped == 0;
+      V.wave_columns = ncol <= H.tune->col_wave_max && V.B.dropped == 0;
       T.lay += secs_since (t_lay0);
    }
    // f32 storage mode: the f64 copy of the level operator was only needed to factor the column blocks
@@ -1085,6 +1087,7 @@ int finalize_host_level (MlHierarchy &H, int l, int nlev, Nat &N, Nat *Cn, int v
    V.L.n = nl;
    V.L.nnz = prow[nl];
    V.L.nrowblk = nrb0 + nrb1;
+   V.L.tune = H.tune;
    T.rb += secs_since (t_rb0);
    auto t_up0 = setup_clk::now ();
    bool ok = upload (&V.L.rowptr, prow.data (), (size_t) nl + 1, &H.device_bytes) &&
@@ -1108,8 +1111,7 @@ int finalize_host_level (MlHierarchy &H, int l, int nlev, Nat &N, Nat *Cn, int v
    if (!ok) ML_FAIL (-2, "multilevel setup: device allocation failed at level %d", l);
    if (l == 0 && !upload (&H.perm0, N.perm.data (), (size_t) nl, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
 
-   static int dense_max = -1;
-   if (dense_max < 0) { const char *e = getenv ("NKP_ML_DENSE_MAX"); dense_max = e ? atoi (e) : 6000; }
+   const int dense_max = H.tune->ml_dense_max;
    // the last level is solved with a dense inverse when it is small enough; otherwise (rough bathymetry can leave
    // thousands of pocket stubs that nothing absorbs) it is relaxed like the others, with many sweeps
    const bool dense_last = (l == nlev - 1) && nl <= dense_max;
@@ -1142,9 +1144,7 @@ int finalize_host_level (MlHierarchy &H, int l, int nlev, Nat &N, Nat *Cn, int v
       std::vector<double> dense ((size_t) nl * nl, 0.0);
       for (int64_t i = 0; i < nl; i++)
          for (int e = prow[i]; e < prow[i + 1]; e++) dense[(size_t) i * nl + pcol[e]] = pval[e];
-      static int host_inverse = -1;
-      if (host_inverse < 0) { const char *e = getenv ("NKP_ML_HOST_INVERSE"); host_inverse = e ? atoi (e) != 0 : 0; }
-      if (host_inverse) {
+      if (H.tune->ml_host_inverse) {
          if (!dense_inverse ((int) nl, dense)) ML_FAIL (-4, "multilevel setup: coarsest operator is singular");
          if (!upload (&H.coarse_inv, dense.data (), dense.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
       } else if (!dense_inverse_device ((int) nl, dense, &H.coarse_inv, &H.device_bytes, st))
@@ -1208,6 +1208,7 @@ int finalize_device_level (MlHierarchy &H, int l, DevLevel &D, Nat &N, const int
    if (rc) ML_FAIL (-2, "multilevel setup: colour-major operator of level %d failed on the device (HIP error %d)", l, rc);
    V.L.n = nl;
    V.L.nnz = D.L.nnz;
+   V.L.tune = H.tune;
    V.L.rowptr = prow;
    V.L.colind = pcol;
    V.L.val = pval;
@@ -1281,34 +1282,36 @@ int finalize_device_level (MlHierarchy &H, int l, DevLevel &D, Nat &N, const int
 
 int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, const double *val,
               const int *blk_start_in, int64_t nblk, const int *col_i, const int *col_j, const int *col_t, int tracer_cnt, int max_levels, int nu, int coarsest_rows, int verbose, int rank,
-              hipStream_t st, char *err, size_t errlen, const CsrDev *A_dev)
+              hipStream_t st, char *err, size_t errlen, const nkp_tuning &tune, const CsrDev *A_dev)
 {
    DevTimes T;
    SetupTimes TH;
+   H.tune = &tune;                                // the caller's (solver's) copy outlives the hierarchy
+   use_setup_knobs (tune);
    H.nu = nu < 1 ? 1 : nu;
-   H.f32 = 1;                                     // level operators and factors stored in f32, arithmetic in f64
-   if (const char *e = getenv ("NKP_ML_F32")) H.f32 = atoi (e) != 0;
+   H.f32 = tune.ml_f32 != 0;                      // level operators and factors stored in f32, arithmetic in f64
    // one launch per half sweep (gs_fused_kernel): bit-identical, but measured slower than the two tuned kernels -- 1 degree
    // cycle 3.62 against 2.65 ms, 3 degree 1.56 against 1.26 ms: a workgroup walks its group's 2-3 row blocks one after the
    // other, each exposing the stream -> gather -> row-sum latency chain that the standalone SpMV hides with one block per
-   // workgroup and hundreds of workgroups in flight -- so it stays off (NKP_ML_FUSED=1 turns it on)
-   H.fused = 0;
-   if (const char *e = getenv ("NKP_ML_FUSED")) H.fused = atoi (e) != 0;
-   H.nu_coarse = H.nu;
-   if (const char *e = getenv ("NKP_ML_SMOOTH_COARSE")) { const int v = atoi (e); if (v >= 1) H.nu_coarse = v; }
-   if (const char *e = getenv ("NKP_ML_COARSE_FROM")) { const int v = atoi (e); if (v >= 1) H.coarse_from = v; }
+   // workgroup and hundreds of workgroups in flight -- so it stays off (ml_fused = 1 turns it on)
+   H.fused = tune.ml_fused != 0;
+   H.nu_coarse = tune.ml_smooth_coarse >= 1 ? tune.ml_smooth_coarse : H.nu;
+   if (tune.ml_coarse_from >= 1) H.coarse_from = tune.ml_coarse_from;
+   // 1.1: the Galerkin operators of piecewise-constant cells are too stiff where lateral mixing matters, so a slightly
+   // over-weighted coarse correction helps (1 degree: 0.9 -> 77 iterations, 1.0 -> 69, 1.1 -> 64, 1.2 -> 68, 1.35 -> 95)
+   H.omega = tune.ml_omega > 0.0 ? tune.ml_omega : 1.1;
+   H.gamma_from = tune.ml_gamma_from;
+   H.gamma_to = tune.ml_gamma_to;
    if (max_levels <= 0) max_levels = 12;
-   const PlanKnobs K = read_plan_knobs ();
+   const PlanKnobs K = plan_knobs (tune);
    const auto t_begin = setup_clk::now ();
 
    // Levels with at least dev_min rows are built by the kernels of mlsetup.hip, the rest by the host routines above (a
    // level of a few 10^4 rows costs less on the host than the launches and round trips of the device passes); both build
    // the same hierarchy entry for entry.  The device passes cover the default construction only: geometric groups with
    // connectivity-aware cells, no edge threshold, no 2-byte column codes, no fused half sweeps.
-   int64_t dev_min = 100000;
-   if (const char *e = getenv ("NKP_ML_DEVICE_MIN")) dev_min = atoll (e);
-   const bool codes = getenv ("NKP_SPMV_COMPRESS") && atoi (getenv ("NKP_SPMV_COMPRESS")) != 0;
-   const bool device_ok = col_i && col_j && K.split && K.theta == 0.0 && !codes && !H.fused && dev_min >= 0;
+   const int64_t dev_min = tune.ml_device_min;
+   const bool device_ok = col_i && col_j && K.split && K.theta == 0.0 && !tune.spmv_compress && !H.fused && dev_min >= 0;
 
    std::vector<Nat> hnat;              // host-built levels (the first of them may have been handed over by the device path)
    int l0 = 0;                         // index of hnat[0] in the hierarchy
@@ -1439,8 +1442,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
    }
    {
       // the small end of the cycle in one single-workgroup launch: the last levels whose rows add up to <= NKP_ML_TAIL_ROWS
-      int64_t cap = 0;             // off: measured 1.7-5x SLOWER (1 degree cycle 4.57 against 2.68 ms) -- one workgroup is latency-bound on a single CU
-      if (const char *e = getenv ("NKP_ML_TAIL_ROWS")) cap = atoll (e);
+      const int64_t cap = tune.ml_tail_rows;   // 0 = off: measured 1.7-5x SLOWER (1 degree cycle 4.57 against 2.68 ms) -- one workgroup is latency-bound on a single CU
       H.tail_from = -1;
       int64_t rows = 0;
       for (int l = nlev - 1; l >= 0 && nlev - l <= 8; l--) {
@@ -1513,14 +1515,6 @@ static void gs_sweep (const MlHierarchy &H, MlLevel &V, bool reverse, bool fused
 
 static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
 {
-   if (H.omega == 0.0) {
-      const char *e = getenv ("NKP_ML_OMEGA");
-      // 1.1: the Galerkin operators of piecewise-constant cells are too stiff where lateral mixing matters, so a slightly
-      // over-weighted coarse correction helps (1 degree: 0.9 -> 77 iterations, 1.0 -> 69, 1.1 -> 64, 1.2 -> 68, 1.35 -> 95)
-      H.omega = (e && atof (e) > 0.0) ? atof (e) : 1.1;
-      if ((e = getenv ("NKP_ML_GAMMA_FROM"))) H.gamma_from = atoi (e);
-      if ((e = getenv ("NKP_ML_GAMMA_TO"))) H.gamma_to = atoi (e);
-   }
    MlLevel &V = H.lev[l];
    V.cur[0] = V.cur[1] = 0;
    if (l == H.tail_from && H.coarse_inv && H.gamma_to <= H.gamma_from && ml_tail_launch (H, l, st) == 0) return;
@@ -1530,17 +1524,15 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
          return;
       }
       // no dense inverse: many sweeps of the column smoother from x = 0 (what is left here is diagonally dominant)
-      static int sweeps = -1;
-      if (sweeps < 0) { const char *e = getenv ("NKP_ML_COARSEST_SWEEPS"); sweeps = (e && atoi (e) > 0) ? atoi (e) : 30; }
+      const int sweeps = H.tune->ml_coarsest_sweeps > 0 ? H.tune->ml_coarsest_sweeps : 30;
       launch_fill (V.x, 0.0, V.n, st);
       column_solves (H, V, 0, V.b, V.x, 0, st);
       gs_half (H, V, 1, false, st);
       for (int s = 1; s < sweeps; s++) gs_sweep (H, V, s & 1, false, st);
       return;
    }
-   // NKP_ML_FUSED_MAX_COLS: the fused half sweep only on levels with at most that many columns (the launch-bound end)
-   static int fused_max = -1;
-   if (fused_max < 0) { const char *e = getenv ("NKP_ML_FUSED_MAX_COLS"); fused_max = e ? atoi (e) : 0; }
+   // ml_fused_max_cols: the fused half sweep only on levels with at most that many columns (the launch-bound end)
+   const int fused_max = H.tune->ml_fused_max_cols;
    const bool fused = H.fused && V.B.gs_ok && (fused_max <= 0 || V.color_grp[2] * V.B.gw <= fused_max);
    // pre-smoothing from x = 0: the first half-sweep needs no SpMV (r = b on colour 0)
    launch_fill (V.x, 0.0, V.n, st);

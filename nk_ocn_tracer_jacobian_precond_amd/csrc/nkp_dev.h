@@ -3,6 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/nkp.h"
+
+// the tuning a launcher uses when its object carries none: the plain defaults (no environment)
+const nkp_tuning &nkp_builtin_tuning ();
+
 #define NKP_LDSRES_CH 16         // substitution steps per factor chunk of colblock_apply_ldsres_kernel (group lengths are padded to it)
 #define NKP_WAVE 64
 #define NKP_MAX_K 512           // most basis vectors a fused update kernel takes (LDS coefficients)
@@ -27,6 +32,7 @@ struct CsrDev {
    unsigned short *codes = nullptr;   // [nnz]
    int *dict = nullptr;
    int *dict_ptr = nullptr;           // [nrowblk+1]
+   const nkp_tuning *tune = nullptr;  // launch shape knobs of the owning solver (NULL: built-in defaults)
 };
 
 // host helper: build the codes for a CSR matrix and its row blocks; returns the fraction of entries coded
@@ -79,6 +85,7 @@ struct ColBlocksDev {
    int gs_lds_bytes = 0;
    int *gs_rb_ptr = nullptr;   // [ngrp+1] first row-block boundary of the group
    int *gs_rb = nullptr;       // row-block boundaries (rows), groups back to back
+   const nkp_tuning *tune = nullptr;   // kernel selection knobs of the owning solver (NULL: built-in defaults)
 };
 
 #define GS_THREADS 256

@@ -74,11 +74,83 @@ extern "C" int nkp_default_options (nkp_options *opt)
    return NKP_OK;
 }
 
+// ---------------------------------------------------------------- tuning knobs (include/nkp.h: nkp_tuning)
+static void builtin_tuning (nkp_tuning *t)
+{
+   memset (t, 0, sizeof *t);
+   t->struct_size = (int) sizeof (nkp_tuning);
+   t->ml_split = 1; t->ml_pocket = 4; t->ml_big_from = -3; t->ml_coarsest_rows = 3000; t->ml_dense_max = 6000;
+   t->ml_theta = 0.0; t->ml_tau = 0.01; t->ml_device_min = 100000;
+   t->ml_smooth_coarse = 0; t->ml_coarse_from = 2; t->ml_gamma_from = 0; t->ml_gamma_to = 0; t->ml_f32 = 1; t->ml_host_inverse = 0;
+   t->ml_fused = 0; t->ml_fused_max_cols = 0; t->ml_coarsest_sweeps = 30; t->ml_tail_rows = 0; t->ml_omega = 1.1;
+   t->col_ldsres = 2; t->col_stream = 1; t->col_stream_min = -1; t->col_stream_gw = 32; t->col_wave_max = 8192; t->col_w3 = 1;
+   t->col_group = 8; t->col_pipe_min = 0; t->col_ldsres_early = 0;
+   t->spmv_variant = 4; t->spmv_compress = 0; t->spmv_pipe_min = 1024; t->spmv_run = 1; t->spmv_wgs = 256;
+   t->precond_steps = 0; t->equil = -1; t->dist_overlap = 1; t->dist_ras = 1; t->force_dist = 0; t->setup_threads = 0; t->plan_times = 0;
+   t->ml_drop_intertracer = 0;
+}
+
+const nkp_tuning &nkp_builtin_tuning ()
+{
+   static const nkp_tuning t = [] { nkp_tuning q; builtin_tuning (&q); return q; } ();
+   return t;
+}
+
+extern "C" int nkp_default_tuning (nkp_tuning *t)
+{
+   if (!t) return NKP_EINVAL;
+   builtin_tuning (t);
+   const char *e;
+#define ENV_INT(name, field) do { if ((e = getenv (name)) && *e) t->field = atoi (e); } while (0)
+#define ENV_POS(name, field) do { if ((e = getenv (name)) && atoi (e) > 0) t->field = atoi (e); } while (0)
+#define ENV_FLAG(name, field) do { if ((e = getenv (name)) && *e) t->field = atoi (e) != 0; } while (0)
+   ENV_FLAG ("NKP_ML_SPLIT", ml_split); ENV_INT ("NKP_ML_POCKET", ml_pocket); ENV_INT ("NKP_ML_BIG_FROM", ml_big_from);
+   ENV_INT ("NKP_ML_COARSEST_ROWS", ml_coarsest_rows); ENV_INT ("NKP_ML_DENSE_MAX", ml_dense_max);
+   if ((e = getenv ("NKP_ML_THETA")) && *e) t->ml_theta = atof (e);
+   if ((e = getenv ("NKP_ML_TAU")) && *e) t->ml_tau = atof (e);
+   if ((e = getenv ("NKP_ML_DEVICE_MIN")) && *e) t->ml_device_min = atoll (e);
+   ENV_POS ("NKP_ML_SMOOTH_COARSE", ml_smooth_coarse); ENV_POS ("NKP_ML_COARSE_FROM", ml_coarse_from);
+   ENV_INT ("NKP_ML_GAMMA_FROM", ml_gamma_from); ENV_INT ("NKP_ML_GAMMA_TO", ml_gamma_to);
+   ENV_FLAG ("NKP_ML_F32", ml_f32); ENV_FLAG ("NKP_ML_HOST_INVERSE", ml_host_inverse); ENV_FLAG ("NKP_ML_FUSED", ml_fused);
+   ENV_INT ("NKP_ML_FUSED_MAX_COLS", ml_fused_max_cols); ENV_POS ("NKP_ML_COARSEST_SWEEPS", ml_coarsest_sweeps);
+   if ((e = getenv ("NKP_ML_TAIL_ROWS")) && *e) t->ml_tail_rows = atoll (e);
+   if ((e = getenv ("NKP_ML_OMEGA")) && atof (e) > 0.0) t->ml_omega = atof (e);
+   ENV_INT ("NKP_COL_LDSRES", col_ldsres); ENV_FLAG ("NKP_COLSTREAM", col_stream); ENV_INT ("NKP_COLSTREAM_MIN", col_stream_min);
+   if ((e = getenv ("NKP_COLSTREAM_GW")) && *e) t->col_stream_gw = atoi (e) == 64 ? 64 : 32;
+   ENV_INT ("NKP_COLWAVE_MAX", col_wave_max); ENV_FLAG ("NKP_COL_W3", col_w3); ENV_INT ("NKP_COLGROUP", col_group);
+   ENV_INT ("NKP_COLPIPE_MIN", col_pipe_min); ENV_FLAG ("NKP_LDSRES_EARLY", col_ldsres_early);
+   ENV_INT ("NKP_SPMV_VARIANT", spmv_variant); ENV_FLAG ("NKP_SPMV_COMPRESS", spmv_compress); ENV_INT ("NKP_SPMV_PIPE_MIN", spmv_pipe_min);
+   ENV_POS ("NKP_SPMV_RUN", spmv_run); ENV_POS ("NKP_SPMV_WGS", spmv_wgs);
+   ENV_POS ("NKP_PRECOND_STEPS", precond_steps); ENV_FLAG ("NKP_EQUIL", equil);
+   ENV_FLAG ("NKP_DIST_OVERLAP", dist_overlap); ENV_FLAG ("NKP_DIST_RAS", dist_ras);
+   if (getenv ("NKP_FORCE_DIST")) t->force_dist = 1;
+   ENV_POS ("NKP_SETUP_THREADS", setup_threads);
+   if (getenv ("NKP_ML_PLAN_TIMES")) t->plan_times = 1;
+   ENV_FLAG ("NKP_ML_DROP_INTERTRACER", ml_drop_intertracer);
+#undef ENV_INT
+#undef ENV_POS
+#undef ENV_FLAG
+   if (t->spmv_variant < 0 || t->spmv_variant > 8) t->spmv_variant = 4;
+   return NKP_OK;
+}
+
+// the caller's knobs, or the defaults + environment (the one place a solver looks at the environment)
+static int resolve_tuning (const nkp_options *opt, nkp_tuning *out)
+{
+   if (opt && opt->tuning) {
+      if (opt->tuning->struct_size != (int) sizeof (nkp_tuning)) return fail (NKP_EINVAL, "nkp_tuning.struct_size mismatch (%d != %zu)", opt->tuning->struct_size, sizeof (nkp_tuning));
+      *out = *opt->tuning;
+      return NKP_OK;
+   }
+   return nkp_default_tuning (out);
+}
+
 // ---------------------------------------------------------------- solver object
 #define NKP_BERR_ROUNDING_LEVEL 1.0e-14     // 45 eps
 
 struct nkp_solver {
    nkp_options opt;
+   nkp_tuning tune;             // resolved once in nkp_create; the matrix, column-block and hierarchy objects point at it
    int device = 0;
    bool stagnated = false;      // last solve stopped by the attainable-accuracy guard
    bool borrowed = false;       // nkp_clone: matrix, factors and hierarchy belong to the solver this one was cloned from
@@ -300,6 +372,9 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    if (opt.restart > NKP_MAX_K - 2) opt.restart = NKP_MAX_K - 2;
    if (opt.precond != NKP_PRECOND_NONE && opt.precond != NKP_PRECOND_COLUMN_JACOBI && opt.precond != NKP_PRECOND_MULTILEVEL)
       return fail (NKP_EINVAL, "nkp_create: unknown preconditioner %d", opt.precond);
+   nkp_tuning tune;
+   { const int trc = resolve_tuning (&opt, &tune); if (trc) return trc; }
+   opt.tuning = nullptr;            // the caller's struct is not kept
    // host-side validation of what the kernels will trust (row chunks in parallel; the lowest offending row is reported)
    {
       struct Bad { int64_t row = -1; int kind = 0; int col = 0; };
@@ -356,6 +431,9 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    if (hipGetDeviceCount (&ndev) != hipSuccess || ndev == 0) return fail (NKP_EDEVICE, "nkp_create: no HIP device available (this library has no CPU fallback)");
    nkp_solver *s = new nkp_solver;
    s->opt = opt;
+   s->tune = tune;
+   s->A.tune = &s->tune;
+   s->B.tune = &s->tune;
    if (opt.device >= 0) {
       if (opt.device >= ndev) { delete s; return fail (NKP_EDEVICE, "nkp_create: device %d of %d does not exist", opt.device, ndev); }
       if (hipSetDevice (opt.device) != hipSuccess) { delete s; return fail (NKP_EDEVICE, "hipSetDevice(%d) failed", opt.device); }
@@ -385,10 +463,10 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
    // can desynchronise the collectives of the distributed flavour); the option stays
    s->precond_steps = 1;
    if (opt.precond_steps > 0) s->precond_steps = opt.precond_steps;
-   { const char *e = getenv ("NKP_PRECOND_STEPS"); if (e && atoi (e) > 0) s->precond_steps = atoi (e); }
+   if (tune.precond_steps > 0) s->precond_steps = tune.precond_steps;
    s->steps_now = s->precond_steps;
    s->equil = opt.equil > 0;
-   { const char *e = getenv ("NKP_EQUIL"); if (e && opt.equil == 0) s->equil = atoi (e) != 0; }
+   if (tune.equil >= 0 && opt.equil == 0) s->equil = tune.equil != 0;
    if (opt.krylov != NKP_KRYLOV_FGMRES) s->equil = false;
 
    // matrix
@@ -489,7 +567,7 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
       // iteration count on one GPU
       std::vector<int32_t> f_rowptr, f_colind;
       std::vector<double> f_val;
-      if (getenv ("NKP_ML_DROP_INTERTRACER") && atoi (getenv ("NKP_ML_DROP_INTERTRACER")) && coupled_tracer_cnt > 1) {
+      if (tune.ml_drop_intertracer && coupled_tracer_cnt > 1) {
          const int64_t tsl = n / coupled_tracer_cnt;
          f_rowptr.assign ((size_t) n + 1, 0);
          for (int64_t i = 0; i < n; i++) {
@@ -501,11 +579,11 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
          colind = f_colind.data ();
          val = f_val.data ();
       }
-      const int coarsest_rows = getenv ("NKP_ML_COARSEST_ROWS") ? atoi (getenv ("NKP_ML_COARSEST_ROWS")) : 3000;   // dense inverse on the device: one tiny level less at 3 degrees, cycle 1.15 -> 0.96 ms
+      const int coarsest_rows = tune.ml_coarsest_rows;   // 3000: dense inverse on the device, one tiny level less at 3 degrees, cycle 1.15 -> 0.96 ms
       const int mrc = pm ? ml_setup (s->ml, pm->n, pm->rowptr, pm->colind, pm->val, pm->blk_start, pm->nblk, pm->col_i, pm->col_j, pm->col_t, coupled_tracer_cnt, opt.ml_levels,
-                                     opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err)
+                                     opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err, s->tune)
                          : ml_setup (s->ml, n, rowptr, colind, val, blk_start, nblk, blk_default.empty () ? opt.col_i : nullptr, blk_default.empty () ? opt.col_j : nullptr, blk_default.empty () ? opt.col_t : nullptr,
-                                     coupled_tracer_cnt, opt.ml_levels, opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err,
+                                     coupled_tracer_cnt, opt.ml_levels, opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err, s->tune,
                                      // the SpMV's device copy is this very matrix unless the columns were renumbered (distributed flavour) or filtered
                                      (!spmv_mat && f_rowptr.empty ()) ? &s->A : nullptr);
       if (mrc != 0) {
@@ -670,6 +748,9 @@ static int dot_host (nkp_solver *s, const double *x, const double *y, double *ou
    allreduce_dev (s, s->misc_dev () + 2, 1, 0);
    HIPCHK (hipMemcpyAsync (s->hpin, s->misc_dev () + 2, sizeof (double), hipMemcpyDeviceToHost, s->stream));
    HIPCHK (hipStreamSynchronize (s->stream));
+   // a collective that failed on this rank leaves stale halo rows / partial sums behind: no host decision may be taken
+   // on them (the ranks' decisions would diverge and their collective sequences with them)
+   if (s->comm_failed) return fail (NKP_ECOMM, "nkp_solve: a collective of the distributed solve failed");
    *out = s->hpin[0];
    return NKP_OK;
 }
@@ -782,6 +863,7 @@ static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
          arnoldi_step_device (s, j);
          HIPCHK (hipMemcpyAsync (s->hpin, s->h_dev (), (size_t) (j + 2) * sizeof (double), hipMemcpyDeviceToHost, st));
          HIPCHK (hipStreamSynchronize (st));
+         if (s->comm_failed) return fail (NKP_ECOMM, "nkp_solve: a collective of the distributed solve failed (Arnoldi step %d)", its + 1);
          double *hc = &H[(size_t) j * (m + 1)];
          for (int i = 0; i <= j + 1; i++) hc[i] = s->hpin[i];
          for (int i = 0; i < j; i++) {
@@ -970,6 +1052,10 @@ extern "C" int nkp_clone (nkp_solver *src, nkp_solver **out)
    if (!s) return fail (NKP_ENOMEM, "nkp_clone: out of host memory");
    s->borrowed = true;
    s->stagnated = false;
+   s->A.tune = &s->tune;
+   s->B.tune = &s->tune;
+   s->ml.tune = &s->tune;
+   for (MlLevel &L : s->ml.lev) L.L.tune = L.B.tune = &s->tune;
    s->stream = nullptr;
    s->own_stream = false;
    s->device_bytes = 0;
@@ -1208,17 +1294,33 @@ static int dist_plan (DistPlan &D, const nkp_comm_ops *comm, const nkp_options &
    need.assign (P, 0);
    give.assign (P, 0);
    std::vector<int32_t> ones (P, 1);
-   int rc = nkp_dist_plan_host (m_loc, nnz_loc, rowptr_loc, colind_glob, rank, P, starts.data (), colind_ext.data (), halo_rows.data (), &n_halo, need.data ());
-   if (rc) return rc;
+   // Checks that only one rank can fail (its own arguments, what its peers sent it) are followed by an agreement: every
+   // rank learns whether any rank failed and all of them leave together -- a rank that returned alone would leave its
+   // peers blocked in the next exchange, for good with a transport that has no deadline (RCCL).
+   auto agree = [&] (int local_rc, const char *where) -> int {
+      std::vector<int64_t> all (P + 1, 0);
+      std::string mine = local_rc ? g_last_error : std::string ();
+      if (comm->allgather_i64_host (comm->ctx, local_rc ? 1 : 0, all.data ())) return fail (NKP_ECOMM, "nkp_create_dist: allgather failed (%s)", where);
+      if (local_rc) { g_last_error = mine; return local_rc; }
+      for (int p = 0; p < P; p++)
+         if (all[p]) return fail (NKP_ECOMM, "nkp_create_dist: rank %d failed its checks (%s); see its message", p, where);
+      return NKP_OK;
+   };
+   int rc = (starts[(size_t) rank + 1] - starts[(size_t) rank] != m_loc)
+               ? fail (NKP_EINVAL, "nkp_create_dist: m_loc = %lld does not match the next rank's fst_row", (long long) m_loc)
+               : nkp_dist_plan_host (m_loc, nnz_loc, rowptr_loc, colind_glob, rank, P, starts.data (), colind_ext.data (), halo_rows.data (), &n_halo, need.data ());
+   if ((rc = agree (rc, "local rows and halo plan"))) return rc;
    // tell every owner how many and which of its rows this rank reads
    if (comm->alltoallv_i32_host (comm->ctx, need.data (), ones.data (), give.data (), ones.data ())) return fail (NKP_ECOMM, "nkp_create_dist: count exchange failed");
    for (int p = 0; p < P; p++) nsend += give[p];
    send_rows.assign ((size_t) nsend + 1, 0);
    if (comm->alltoallv_i32_host (comm->ctx, halo_rows.data (), need.data (), send_rows.data (), give.data ())) return fail (NKP_ECOMM, "nkp_create_dist: index exchange failed");
+   rc = NKP_OK;
    for (int64_t q = 0; q < nsend; q++) {
       send_rows[q] -= (int32_t) fst_row;
-      if (send_rows[q] < 0 || send_rows[q] >= m_loc) return fail (NKP_ECOMM, "nkp_create_dist: a peer asked for a row this rank does not own");
+      if (send_rows[q] < 0 || send_rows[q] >= m_loc) rc = fail (NKP_ECOMM, "nkp_create_dist: a peer asked for a row this rank does not own");
    }
+   if ((rc = agree (rc, "requested rows"))) return rc;
 
    // ---- restricted additive Schwarz (overlap of one ring of water columns) -------------------------------------------
    // A hierarchy built from the rank's diagonal block alone treats the cut through the ocean as a wall: latitude bands cost
@@ -1231,7 +1333,10 @@ static int dist_plan (DistPlan &D, const nkp_comm_ops *comm, const nkp_options &
    // its block-Jacobi preconditioner): a halo column joins only if its (i, j) is not the position of an own column.
    const bool geo = o.col_i && o.col_j && blk_start_loc && nblk_loc > 0;
    int64_t want_ras = (o.precond == NKP_PRECOND_MULTILEVEL && geo) ? 1 : 0;
-   { const char *e = getenv ("NKP_DIST_RAS"); if (e && atoi (e) == 0) want_ras = 0; }
+   {
+      nkp_tuning tune;
+      if (resolve_tuning (&o, &tune) == NKP_OK && !tune.dist_ras) want_ras = 0;      // a bad tuning struct is reported by the create call itself
+   }
    {
       std::vector<int64_t> all (P + 1, 0);
       if (comm->allgather_i64_host (comm->ctx, want_ras, all.data ())) return fail (NKP_ECOMM, "nkp_create_dist: allgather failed");
@@ -1285,7 +1390,7 @@ static int dist_plan (DistPlan &D, const nkp_comm_ops *comm, const nkp_options &
          bool good = sum == n_halo2;
          for (int64_t k = 1; k < n_halo2 && good; k++) good = halo2[(size_t) k] > halo2[(size_t) k - 1];
          for (int64_t k = 0; k < n_halo && good; k++) good = std::binary_search (halo2.begin (), halo2.begin () + n_halo2, halo_rows[(size_t) k]);
-         if (!good) return fail (NKP_ECOMM, "nkp_create_dist: the completed halo is inconsistent (a water column straddles two ranks?)");
+         if ((rc = agree (good ? NKP_OK : fail (NKP_ECOMM, "nkp_create_dist: the completed halo is inconsistent (a water column straddles two ranks?)"), "completed halo"))) return rc;
       }
       // the SpMV addresses the completed halo from here on
       for (int64_t r = 0; r < m_loc; r++)
@@ -1352,10 +1457,11 @@ static int dist_plan (DistPlan &D, const nkp_comm_ops *comm, const nkp_options &
          for (int p = 0; p < P; p++) {
             int64_t t = 0;
             for (int k = 0; k < erow_need[p]; k++, q++) t += len_r[q];
-            if (2 * t >= 2147483647LL || 2 * (int64_t) ent_give[p] >= 2147483647LL) return fail (NKP_EINVAL, "nkp_create_dist: overlap rows exceed the int32 exchange counts");
+            if (2 * t >= 2147483647LL || 2 * (int64_t) ent_give[p] >= 2147483647LL) { rc = fail (NKP_EINVAL, "nkp_create_dist: overlap rows exceed the int32 exchange counts"); t = 0; ent_give[p] = 0; }
             ent_need[p] = (int) t;
             n_eent += t;
          }
+         if ((rc = agree (rc, "overlap sizes"))) return rc;
          for (int p = 0; p < P; p++) { ent2_give[p] = 2 * ent_give[p]; ent2_need[p] = 2 * ent_need[p]; }
       }
       std::vector<int32_t> col_r ((size_t) n_eent + 1), val_r (2 * (size_t) n_eent + 2);
@@ -1393,7 +1499,7 @@ static int dist_plan (DistPlan &D, const nkp_comm_ops *comm, const nkp_options &
             hpos += len;
          }
       }
-      if (n_sel != n_erow) return fail (NKP_ECOMM, "nkp_create_dist: overlap rows announced and received differ");
+      if ((rc = agree (n_sel != n_erow ? fail (NKP_ECOMM, "nkp_create_dist: overlap rows announced and received differ") : NKP_OK, "overlap rows"))) return rc;
       auto ext_of_global = [&] (int64_t g) -> int64_t {
          if (g >= fst_row && g < fst_row + m_loc) return g - fst_row;
          const auto it = std::lower_bound (halo2.begin (), halo2.begin () + n_halo2, (int32_t) g);
@@ -1519,7 +1625,9 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
 {
    if (!out) return fail (NKP_EINVAL, "nkp_create_dist: out is NULL");
    *out = nullptr;
-   if (!comm || (comm->nranks <= 1 && !getenv ("NKP_FORCE_DIST"))) {
+   nkp_tuning tune;
+   { const int trc = resolve_tuning (opt, &tune); if (trc) return trc; }
+   if (!comm || (comm->nranks <= 1 && !tune.force_dist)) {
       if (fst_row != 0 || m_loc != n_global) return fail (NKP_EINVAL, "nkp_create_dist: a single rank must own all rows");
       return create_impl (out, opt, n_global, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt, nullptr);
    }
@@ -1532,12 +1640,13 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
    starts[P] = n_global;
    for (int p = 0; p < P; p++)
       if (starts[p + 1] < starts[p] || starts[0] != 0) return fail (NKP_EINVAL, "nkp_create_dist: row blocks must be contiguous and ascending over the ranks");
-   if (starts[rank + 1] - starts[rank] != m_loc) return fail (NKP_EINVAL, "nkp_create_dist: m_loc does not match the next rank's fst_row");
+   // (whether m_loc matches the next rank's fst_row is a per-rank finding: dist_plan checks it and all ranks leave together)
 
    nkp_options o;
    if (opt) o = *opt;
    else nkp_default_options (&o);
    o.rank = rank;
+   o.tuning = &tune;               // resolved once for the plan and the create call below
    DistPlan D;
    int rc = dist_plan (D, comm, o, starts, fst_row, m_loc, nnz_loc, rowptr_loc, colind_glob, val, blk_start_loc, nblk_loc, coupled_tracer_cnt);
    if (rc) return rc;
@@ -1589,10 +1698,20 @@ extern "C" int nkp_create_dist (nkp_solver **out, const nkp_options *opt, int64_
       if (ok && n_sel) ok = hipMemcpy (s->dist.sel_idx, sel_hpos.data (), (size_t) n_sel * sizeof (int), hipMemcpyHostToDevice) == hipSuccess;
       s->dist.ras = ok;
    }
-   if (!ok) { solver_free (s); return fail (NKP_ENOMEM, "nkp_create_dist: halo buffers could not be allocated"); }
    {
-      const char *e = getenv ("NKP_DIST_OVERLAP");
-      const bool want = !e || atoi (e) != 0;
+      // once more all ranks together: a rank without halo buffers must not leave its peers to a first SpMV that never completes
+      std::vector<int64_t> all (P + 1, 0);
+      const bool comm_ok = comm->allgather_i64_host (comm->ctx, ok ? 0 : 1, all.data ()) == 0;
+      int bad_rank = -1;
+      for (int p = 0; p < P && comm_ok; p++) if (all[p] && bad_rank < 0) bad_rank = p;
+      if (!ok || !comm_ok || bad_rank >= 0) {
+         solver_free (s);
+         if (!ok) return fail (NKP_ENOMEM, "nkp_create_dist: halo buffers could not be allocated");
+         return fail (NKP_ECOMM, comm_ok ? "nkp_create_dist: halo buffers could not be allocated on rank %d" : "nkp_create_dist: allgather failed (%d)", bad_rank);
+      }
+   }
+   {
+      const bool want = s->tune.dist_overlap != 0;
       const int interior_blocks = s->dist.seg_rb[2] - s->dist.seg_rb[1];
       if (want && interior_blocks > 0 && hipStreamCreateWithFlags (&s->dist.comm_stream, hipStreamNonBlocking) == hipSuccess &&
           hipEventCreateWithFlags (&s->dist.ev_packed, hipEventDisableTiming) == hipSuccess &&

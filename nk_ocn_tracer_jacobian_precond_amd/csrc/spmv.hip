@@ -19,7 +19,7 @@
 #define SPMV_LDS_NNZ NKP_SPMV_LDS_NNZ
 #define SPMV_MAX_ROWS NKP_SPMV_MAX_ROWS
 
-template <int MODE, int VAR, class VT>   // MODE 0: y = A x   1: y = b - A x   2: y = |A||x| + |b| ; VAR: load flavour ; VT: stored value type
+template <int MODE, int VAR, class VT>   // MODE 0: y = A x   1: y = b - A x   2: y = |A||x| + |b| ; VAR: load flavour (5-8: ablation build only) ; VT: stored value type
 __global__ __launch_bounds__ (SPMV_THREADS)
 void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk, int per_xcd,
                              const int *__restrict__ rowptr, const int *__restrict__ colind,
@@ -65,6 +65,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       return;
    }
 
+#ifdef NKP_ABLATION
    if (VAR == 8) {
       // TIMING-ONLY: pure stream of the two arrays, no gather, no LDS, no row sums
       double acc = 0.0;
@@ -73,6 +74,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       if (acc == 123.456) y[r0] = acc;
       return;
    }
+#endif
    // phase 1: coalesced stream of (val, colind), gather x through L2, products staged in LDS
    if (VAR == 4) {
       // 2-byte column codes: 10 instead of 12 bytes per entry off HBM
@@ -116,6 +118,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
             prod[k + 1] = (MODE == 2) ? fabs (q) : q;
          }
       }
+#ifdef NKP_ABLATION
    } else if (VAR >= 5) {
       // TIMING-ONLY ablations (wrong results by design): 5 = no x gather, 6 = no row sums, 7 = no value stream
 #pragma unroll 8
@@ -125,6 +128,7 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
          const double q = v * ((VAR == 5) ? (double) c : x[c]);
          prod[k] = q;
       }
+#endif
    } else {
 #pragma unroll 8
       for (int k = tid; k < cnt; k += SPMV_THREADS) {
@@ -135,10 +139,12 @@ void csr_spmv_stream_kernel (const int *__restrict__ rowblk_all, int rb0, int nr
       }
    }
    __syncthreads ();
+#ifdef NKP_ABLATION
    if (VAR == 6) {
       if (tid == 0) y[r0] = prod[0] + prod[cnt - 1];
       return;
    }
+#endif
 
    // phase 2: one lane per row sums its LDS segment (fixed order => deterministic)
    const int r = r0 + tid;
@@ -329,41 +335,18 @@ void build_rowblocks_host (int64_t n, const int *rowptr, int **rowblk_out, int *
    *nrowblk_out = nb;
 }
 
-static int spmv_variant ()
-{
-   static int v = -1;
-   if (v < 0) {
-      const char *e = getenv ("NKP_SPMV_VARIANT");
-      v = e ? atoi (e) : 4;
-      if (v < 0 || v > 8) v = 4;
-   }
-   return v;
-}
-
-static int spmv_pipe_min ()
-{
-   static int v = -1;
-   if (v < 0) {
-      const char *e = getenv ("NKP_SPMV_PIPE_MIN");
-      v = e ? atoi (e) : 1024;
-   }
-   return v;
-}
-
 template <int MODE>
 static void launch_range (const CsrDev &A, int rb0, int cnt, const double *x, double *y, const double *b, hipStream_t st)
 {
    if (cnt <= 0) return;
    const int per_xcd = (cnt + 7) / 8;
-   if (spmv_variant () == 4 && cnt >= spmv_pipe_min ()) {
-      // how many row blocks one workgroup walks (NKP_SPMV_RUN) and how many workgroups per CU at most (NKP_SPMV_WGS).
+   const nkp_tuning &T = A.tune ? *A.tune : nkp_builtin_tuning ();
+   if (T.spmv_variant == 4 && cnt >= T.spmv_pipe_min) {
+      // how many row blocks one workgroup walks (spmv_run) and how many workgroups per CU at most (spmv_wgs).
       // Same-process A/B at 1 degree, first with runs of >= 3: 6 per CU 199 us, 24 per CU 184 us, 48 per CU 177 us; then
       // runs of 1 with 160-256 per CU: SpMV -1..2 %, V-cycle 2.71 -> 2.63 ms, Arnoldi step (j = 100) 7.02 -> 6.86 ms on
       // two repeats -- enough workgroups in flight hide the stream latency as well as the in-workgroup prefetch does
-      static int per_cu = -1;
-      if (per_cu < 0) { const char *e = getenv ("NKP_SPMV_WGS"); per_cu = (e && atoi (e) > 0) ? atoi (e) : 256; }
-      static int run_len = -1;
-      if (run_len < 0) { const char *e = getenv ("NKP_SPMV_RUN"); run_len = (e && atoi (e) > 0) ? atoi (e) : 1; }
+      const int per_cu = T.spmv_wgs > 0 ? T.spmv_wgs : 256, run_len = T.spmv_run > 0 ? T.spmv_run : 1;
       int wgs = cnt / run_len;
       if (wgs > 256 * per_cu) wgs = 256 * per_cu;
       wgs &= ~7;
@@ -382,17 +365,20 @@ static void launch_range (const CsrDev &A, int rb0, int cnt, const double *x, do
    }
 #define SPMV_GO(VV) hipLaunchKernelGGL ((csr_spmv_stream_kernel<MODE, VV, double>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st, \
                                          A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.val, x, y, b, A.codes, A.dict, A.dict_ptr)
-   int var = spmv_variant ();
+   int var = T.spmv_variant;
    if (var == 4 && !A.codes) var = 0;
    switch (var) {
    case 1: SPMV_GO (1); break;
    case 2: SPMV_GO (2); break;
    case 3: SPMV_GO (3); break;
    case 4: SPMV_GO (4); break;
+#ifdef NKP_ABLATION
+   // timing-only bodies that produce WRONG results by design: never in libnkp_hip.so, only in the `make ablation` library
    case 5: SPMV_GO (5); break;
    case 6: SPMV_GO (6); break;
    case 7: SPMV_GO (7); break;
    case 8: SPMV_GO (8); break;
+#endif
    default: SPMV_GO (0); break;
    }
 #undef SPMV_GO
@@ -477,12 +463,11 @@ double build_spmv_codes_host (int64_t n, const int *rowptr, const int *colind, c
 
 int attach_spmv_codes (CsrDev &A, const int *h_rowptr, const int *h_colind, const int *h_rowblk, size_t *device_bytes)
 {
-   // off by default (NKP_SPMV_COMPRESS=1 turns it on): measured at 1 degree the 2-byte codes do not shorten the
-   // kernels -- pipelined f64 SpMV 0.236 ms coded against 0.203 ms plain on the same box, V-cycle 2.93 against 2.69 ms:
-   // the dictionary lookup sits in front of the x gather and lengthens the dependent chain by more than the 2 bytes
+   // off by default (nkp_tuning.spmv_compress / NKP_SPMV_COMPRESS=1 turns it on): measured at 1 degree the 2-byte codes do not
+   // shorten the kernels -- pipelined f64 SpMV 0.236 ms coded against 0.203 ms plain on the same box, V-cycle 2.93 against
+   // 2.69 ms: the dictionary lookup sits in front of the x gather and lengthens the dependent chain by more than the 2 bytes
    // per entry save -- and building them costs ~2.7 s of setup
-   const char *e = getenv ("NKP_SPMV_COMPRESS");
-   if (!e || atoi (e) == 0) return 0;
+   if (!(A.tune ? A.tune->spmv_compress : 0)) return 0;
    if (A.nnz == 0 || A.nrowblk == 0) return 0;
    unsigned short *codes = nullptr;
    int *dict = nullptr, *dict_ptr = nullptr, nd = 0;

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host", "nkp_set_device",
     "nkp_gather_root", "nkp_clone", "nkp_ml_plan_host", "nkp_comm_file_init", "nkp_comm_file_free",
     "nkp_create64", "nkp_cell_major_order", "nkp_permuted_rows", "nkp_dist_overlap_plan_host", "nkp_dist_plan_size",
-    "nkp_dist_plan_copy", "nkp_dist_plan_free", "nkp_ml_level_array",
+    "nkp_dist_plan_copy", "nkp_dist_plan_free", "nkp_ml_level_array", "nkp_default_tuning",
 ]
 
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
@@ -43,6 +43,22 @@ class NkpCommOps(C.Structure):
                 ("allgather_i64_host", _ALLGATHER_I64_FN)]
 
 
+class NkpTuning(C.Structure):
+    """nkp_tuning (include/nkp.h): the knobs behind the defaults; NKP_* environment variables set the same fields when no struct is passed."""
+    _fields_ = [
+        ("struct_size", C.c_int), ("ml_split", C.c_int), ("ml_pocket", C.c_int), ("ml_big_from", C.c_int), ("ml_coarsest_rows", C.c_int),
+        ("ml_dense_max", C.c_int), ("ml_theta", C.c_double), ("ml_tau", C.c_double), ("ml_device_min", C.c_int64),
+        ("ml_smooth_coarse", C.c_int), ("ml_coarse_from", C.c_int), ("ml_gamma_from", C.c_int), ("ml_gamma_to", C.c_int), ("ml_f32", C.c_int),
+        ("ml_host_inverse", C.c_int), ("ml_fused", C.c_int), ("ml_fused_max_cols", C.c_int), ("ml_coarsest_sweeps", C.c_int),
+        ("ml_tail_rows", C.c_int64), ("ml_omega", C.c_double),
+        ("col_ldsres", C.c_int), ("col_stream", C.c_int), ("col_stream_min", C.c_int), ("col_stream_gw", C.c_int), ("col_wave_max", C.c_int),
+        ("col_w3", C.c_int), ("col_group", C.c_int), ("col_pipe_min", C.c_int), ("col_ldsres_early", C.c_int),
+        ("spmv_variant", C.c_int), ("spmv_compress", C.c_int), ("spmv_pipe_min", C.c_int), ("spmv_run", C.c_int), ("spmv_wgs", C.c_int),
+        ("precond_steps", C.c_int), ("equil", C.c_int), ("dist_overlap", C.c_int), ("dist_ras", C.c_int), ("force_dist", C.c_int),
+        ("setup_threads", C.c_int), ("plan_times", C.c_int), ("ml_drop_intertracer", C.c_int),
+    ]
+
+
 class NkpOptions(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int), ("precond", C.c_int), ("krylov", C.c_int), ("restart", C.c_int),
@@ -50,6 +66,7 @@ class NkpOptions(C.Structure):
         ("verbose", C.c_int), ("rank", C.c_int), ("reorth", C.c_int), ("ml_levels", C.c_int),
         ("ml_smooth", C.c_int), ("basis_f32", C.c_int), ("precond_steps", C.c_int), ("equil", C.c_int), ("reserved", C.c_int * 4),
         ("col_i", C.POINTER(C.c_int32)), ("col_j", C.POINTER(C.c_int32)), ("col_t", C.POINTER(C.c_int32)),
+        ("tuning", C.POINTER(NkpTuning)),
     ]
 
 
@@ -153,6 +170,19 @@ def default_options(**overrides):
     return o
 
 
+def default_tuning(**overrides):
+    """nkp_default_tuning (defaults + NKP_* environment) with keyword overrides; pass the result as NkpSolver(..., tuning=t)."""
+    lib = load_library()
+    t = NkpTuning()
+    lib.nkp_default_tuning.argtypes = [C.POINTER(NkpTuning)]
+    lib.nkp_default_tuning(C.byref(t))
+    for k, v in overrides.items():
+        if not hasattr(t, k):
+            raise AttributeError(f"nkp_tuning has no field {k}")
+        setattr(t, k, v)
+    return t
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
@@ -213,8 +243,12 @@ class NkpSolver:
         val = np.ascontiguousarray(val, np.float64)
         self.n = int(rowptr.size - 1)
         self.nnz = int(colind.size)
+        tuning = options.pop("tuning", None)
         opt = default_options(**options)
         self.options = opt
+        if tuning is not None:                                 # an NkpTuning, or a dict of overrides on top of the defaults + environment
+            self._tuning = tuning if isinstance(tuning, NkpTuning) else default_tuning(**tuning)
+            opt.tuning = C.pointer(self._tuning)
         if col_i is not None and col_j is not None:
             col_i = np.ascontiguousarray(col_i, np.int32)
             col_j = np.ascontiguousarray(col_j, np.int32)

@@ -113,6 +113,19 @@ def main():
             result["hanging"] = "caught: " + str(exc)[:60]
         time.sleep(7.0)                                   # let the abandoned helper thread finish before the group goes away
         result["sound_again"] = bool(nd.comm_self_test(comm, timeout=60.0))
+    elif a.mode == "cpu-plan-fail":
+        # one rank's input is broken (a column index beyond the matrix): that rank reports its own finding, every other rank
+        # learns that a peer failed, and ALL of them return -- nobody is left waiting in the next exchange
+        bad_rank = world - 1
+        if rank == bad_rank:
+            loc["colind"] = loc["colind"].copy()
+            loc["colind"][0] = n + 5
+        try:
+            nd.overlap_plan_host(loc, n, comm, 1)
+            result["code"], result["message"] = 0, ""
+        except solver.NkpError as exc:
+            result["code"], result["message"] = exc.code, str(exc)
+        result["bad_rank"] = bad_rank
     elif a.mode == "cpu-overlap-plan":
         # nkp_create_dist's whole host-side plan (no GPU): completed halo, overlap selection, the matrix of the hierarchy
         import scipy.sparse as sp

@@ -39,6 +39,18 @@ def lib():
                                  f64p, f64p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.ora_direct_solve.argtypes = [C.c_int64, i32p, i32p, f64p, f64p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.ora_num_threads.restype = C.c_int
+        L.ora_ml_setup.argtypes = [C.c_int64, i32p, i32p, f64p, C.c_int64, i32p, i32p, i32p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ora_ml_setup.restype = C.c_void_p
+        L.ora_ml_free.argtypes = [C.c_void_p]
+        L.ora_ml_levels.argtypes = [C.c_void_p]
+        L.ora_ml_level_rows.argtypes = [C.c_void_p, C.c_int]
+        L.ora_ml_level_rows.restype = C.c_int64
+        L.ora_ml_level_nnz.argtypes = [C.c_void_p, C.c_int]
+        L.ora_ml_level_nnz.restype = C.c_int64
+        L.ora_ml_level_maps.argtypes = [C.c_void_p, C.c_int, i32p, i32p]
+        L.ora_ml_apply.argtypes = [C.c_void_p, f64p, f64p]
+        L.ora_ml_fgmres.argtypes = [C.c_void_p, C.c_int64, i32p, i32p, f64p, C.c_int, C.c_int, C.c_double, C.c_int, f64p, f64p,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -137,3 +149,49 @@ def rowblock_partition(n, nprocs, rank):
 
 def num_threads():
     return lib().ora_num_threads()
+
+
+class MlOracle:
+    """The multilevel water-column preconditioner + FGMRES of oracle/ml_oracle.c (C / OpenMP, all host cores)."""
+
+    def __init__(self, rowptr, colind, val, blk_start, col_i, col_j, coupled_tracer_cnt=1, nu=3, coarsest_rows=3000, max_levels=0):
+        self.rp, self.ci, self.v = _csr(rowptr, colind, val)
+        self.n = self.rp.size - 1
+        blk = np.ascontiguousarray(blk_start, np.int32)
+        self._h = lib().ora_ml_setup(self.n, self.rp, self.ci, self.v, blk.size - 1, blk, np.ascontiguousarray(col_i, np.int32),
+                                     np.ascontiguousarray(col_j, np.int32), coupled_tracer_cnt, nu, coarsest_rows, max_levels)
+        if not self._h:
+            raise RuntimeError("ora_ml_setup failed")
+
+    def levels(self):
+        L = lib()
+        return [(int(L.ora_ml_level_rows(self._h, l)), int(L.ora_ml_level_nnz(self._h, l))) for l in range(L.ora_ml_levels(self._h))]
+
+    def maps(self, l):
+        rows = self.levels()[l][0]
+        cmap, col_of = np.full(rows, -1, np.int32), np.empty(rows, np.int32)
+        lib().ora_ml_level_maps(self._h, l, cmap, col_of)
+        return cmap, col_of
+
+    def apply(self, r):
+        z = np.empty(self.n)
+        lib().ora_ml_apply(self._h, np.ascontiguousarray(r, np.float64), z)
+        return z
+
+    def fgmres(self, b, restart=200, max_iters=20000, rtol=1e-10, reorth=0):
+        x = np.empty(self.n)
+        its, rr = C.c_int(), C.c_double()
+        status = lib().ora_ml_fgmres(self._h, self.n, self.rp, self.ci, self.v, restart, max_iters, rtol, reorth,
+                                     np.ascontiguousarray(b, np.float64), x, C.byref(its), C.byref(rr))
+        return x, dict(status=status, iters=its.value, relres=rr.value)
+
+    def close(self):
+        if self._h:
+            lib().ora_ml_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

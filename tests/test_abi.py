@@ -85,3 +85,28 @@ def test_create64_refuses_what_one_gpu_cannot_index():
     rp = np.array([0, 3, 2], np.int64)
     rc = lib.nkp_create64(C.byref(h), None, 2, rp.ctypes.data_as(C.POINTER(C.c_int64)), None, None, None, 0, 1)
     assert rc == -1 and "out of range" in solver.last_error()
+
+
+def test_no_ablation_kernels_in_the_shipped_library():
+    """The SpMV's timing-only bodies (NKP_SPMV_VARIANT 5..8: results wrong by design) are compiled only into the separate
+    `make ablation` library, never into libnkp_hip.so / the executables."""
+    out = subprocess.run(["nm", "-C", solver.HIP_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    kernels = [ln for ln in out.splitlines() if "csr_spmv_stream_kernel<" in ln]
+    assert kernels, "the SpMV kernels should be visible to nm"
+    assert not [ln for ln in kernels if re.search(r"csr_spmv_stream_kernel<\d+, [5-8],", ln)]
+
+
+def test_kernels_and_cycle_do_not_read_the_environment():
+    """Tuning knobs reach the kernels through nkp_tuning, resolved once per nkp_create (csrc/solver.hip: nkp_default_tuning);
+    no launcher, cycle or setup routine calls getenv."""
+    csrc = os.path.join(ROOT, "nk_ocn_tracer_jacobian_precond_amd", "csrc")
+    for name in ("spmv.hip", "colblock.hip", "multilevel.hip", "mlsetup.hip", "mltail.hip", "blas1.hip"):
+        assert "getenv" not in open(os.path.join(csrc, name)).read(), name
+    text = open(os.path.join(csrc, "solver.hip")).read()
+    body = text[text.index('extern "C" int nkp_default_tuning'):text.index("static int resolve_tuning")]
+    assert text.count("getenv") == body.count("getenv")
+
+
+def test_tuning_struct_round_trip():
+    t = solver.default_tuning(ml_pocket=6)
+    assert t.struct_size == C.sizeof(solver.NkpTuning) and t.ml_pocket == 6 and t.ml_omega == 1.1 and t.spmv_variant == 4

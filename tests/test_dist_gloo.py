@@ -192,3 +192,29 @@ def test_overlap_plan_over_gloo(tmp_path, world, partition):
     else:
         assert all(r["ras"] == 1 for r in res) and sum(r["n_sel"] for r in res) > 0, res
         assert all(r["sel_rows_ok"] and r["ext_matrix_ok"] and r["blocks_ok"] and r["coords_ok"] and r["tracers_ok"] for r in res), res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_plan_failure_on_one_rank_ends_every_rank(tmp_path, world):
+    """A rank-local failure inside nkp_create_dist's host plan (here: one rank holds a column index outside the matrix) must
+    not strand the other ranks in the next exchange: the plan agrees on success after every rank-local check, the failing
+    rank returns its own error (NKP_EINVAL) and every peer NKP_ECOMM naming it.  The launch itself has a deadline: a hang
+    fails the test."""
+    res = launch(world, "cpu-plan-fail", str(tmp_path / "pfail"))
+    bad = res[0]["bad_rank"]
+    for r in res:
+        if r["rank"] == bad:
+            assert r["code"] == -1 and "out of range" in r["message"], r
+        else:
+            assert r["code"] == -5 and f"rank {bad} failed" in r["message"], r
+
+
+@pytest.mark.parametrize("world,partition", [(8, "bands"), (8, "cells")])
+def test_overlap_plan_world_8(tmp_path, world, partition):
+    """The driver's scaling run goes to 8 ranks: the same host-side plan checks as above with 8 processes -- configs[4]'s
+    latitude bands and configs[3]'s cell-major bands of a coupled system (a 2-tracer stand-in on a grid with 8 bands of
+    at least three latitude rows)."""
+    res = launch(world, "cpu-overlap-plan", str(tmp_path / "oplan8"), extra=("--partition", partition, "--grid", "24x40x8"))
+    assert all(r["halo_complete"] and r["spmv_bit_exact"] for r in res), res
+    assert all(r["ras"] == 1 for r in res) and sum(r["n_sel"] for r in res) > 0, res
+    assert all(r["sel_rows_ok"] and r["ext_matrix_ok"] and r["blocks_ok"] and r["coords_ok"] and r["tracers_ok"] for r in res), res
