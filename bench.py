@@ -71,6 +71,26 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpu_share():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands each job a
+    share of its cores; OpenMP would otherwise start one spinning thread per core of the machine)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("NKP_BENCH_CPU_THREADS")
+    return int(env) if env else n
+
+
 def cpu_complete_solve(p, blk, ci, cj, rtol, restart):
     """ONE complete solve of the bench workload itself on the host, with the SAME algorithm the GPU runs -- low-order twin,
     connectivity-aware 2 x 2 aggregation, Galerkin operators, 2-colour water-column Gauss-Seidel V(3,3) cycle, FGMRES --
@@ -78,7 +98,8 @@ def cpu_complete_solve(p, blk, ci, cj, rtol, restart):
     cores.  Measured, not extrapolated; the right-hand side is drawn like the GPU's (standard normal)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ora
-    cores = ora.num_threads()
+    cores = host_cpu_share()
+    ora.set_num_threads(cores)
     t0 = time.perf_counter()
     M = ora.MlOracle(p.rowptr, p.colind, p.nzval, blk, ci, cj)
     t_setup = time.perf_counter() - t0
@@ -372,7 +393,7 @@ def main():
     kernels = []
     if not distributed:
         for label, which, key, reps in (("csr_spmv_pipe_kernel<1, float> (smoother residual rows, fine level, one colour)", 3, "smoother_spmv_bytes", 100),
-                                        ("colblock_apply_ldsres_kernel (water-column solves, fine level, one colour)", 4, "column_solve_bytes", 100),
+                                        ("colblock_apply_ldspack_kernel (water-column solves, fine level, one colour)", 4, "column_solve_bytes", 100),
                                         ("whole V-cycle (all levels, ~150 launches)", 1, "cycle_bytes", 50)):
             ms = pre_ms if which == 1 else s.time_kernel(which, reps=reps)
             nbytes = s.get_int(key)

@@ -90,6 +90,7 @@ typedef struct nkp_tuning {
    int ml_host_inverse;      /* NKP_ML_HOST_INVERSE (0): dense inverse of the last level on the host */
    int ml_fused;             /* NKP_ML_FUSED (0): one launch per Gauss-Seidel half sweep */
    int ml_fused_max_cols;    /* NKP_ML_FUSED_MAX_COLS (0 = all): ... only on levels with at most that many columns */
+   int ml_wave_fused;        /* NKP_ML_WAVE_FUSED (1): levels solved one column per wave run each half sweep as ONE launch */
    int ml_coarsest_sweeps;   /* NKP_ML_COARSEST_SWEEPS (30): sweeps on a last level too large for a dense inverse */
    int64_t ml_tail_rows;     /* NKP_ML_TAIL_ROWS (0): the last levels with at most that many rows in one launch */
    double ml_omega;          /* NKP_ML_OMEGA (1.1): weight of the coarse-grid correction */
@@ -103,6 +104,7 @@ typedef struct nkp_tuning {
    int col_group;            /* NKP_COLGROUP (8) */
    int col_pipe_min;         /* NKP_COLPIPE_MIN (0 = off) */
    int col_ldsres_early;     /* NKP_LDSRES_EARLY (0) */
+   int col_ldsres_packed;    /* NKP_COL_PACKED (1): LDS-resident column kernel with factors packed four steps to a 16-byte load */
    /* ---- CSR SpMV launch shape */
    int spmv_variant;         /* NKP_SPMV_VARIANT (4) */
    int spmv_compress;        /* NKP_SPMV_COMPRESS (0): 2-byte column codes */

@@ -227,6 +227,115 @@ void colblock_apply_kernel (const int *__restrict__ blk_start, int b_first, int 
    }
 }
 
+// ---------------------------------------------------------------- fused half sweep, one water column per wave
+// Small levels of the multilevel cycle (a few thousand columns) run at the latency floor of their launches: a residual SpMV
+// over the colour's rows (~7 us) followed by the wave-per-column solve above (~11 us), both far below one wave per SIMD.
+// Here ONE launch does both for one colour: lane l of the wave that owns a column computes the residual of ITS row straight
+// from the CSR arrays (row-per-lane: a level of this size sits in L2 / MALL, so the uncoalesced row reads cost latency, not
+// bandwidth, and the loads of 8 entries are in flight together), then the wave runs the band substitution on the
+// residual it holds in registers, and x_new = x_old + z goes out.  r never touches memory and half of the launches go.
+// x comes from TWO buffers like gs_fused_kernel's (rows < split from xa, the others from xb; new values to xout): columns
+// of one colour are coupled, so the sweep must not see its own updates (multilevel.hip ping-pongs the buffers).
+// Same products, same per-row summation order, same substitution as the two-kernel path => identical bits.
+#define GSW_UNROLL 32
+template <int P, int RPL, class VT, bool R32>
+__global__ __launch_bounds__ (CB_THREADS)
+void gs_wave_kernel (const int *__restrict__ rowptr, const int *__restrict__ colind, const VT *__restrict__ val,
+                     const int *__restrict__ blk_start, int b_first, int b_end, int64_t n, const double *__restrict__ fac,
+                     const double *__restrict__ xa, const double *__restrict__ xb, int split, const double *__restrict__ b, double *__restrict__ xout)
+{
+   const int blk = wave_block_id () + b_first;
+   if (blk >= b_end) return;
+   const int lane = threadIdx.x & (NKP_WAVE - 1);
+   const int r0 = blk_start[blk];
+   const int len = blk_start[blk + 1] - r0;
+
+   double y[RPL], xold[RPL], invd[RPL], L[RPL][P], U[RPL][P];
+   int e0[RPL], rl[RPL];
+#pragma unroll
+   for (int s = 0; s < RPL; s++) {
+      const int li = s * NKP_WAVE + lane;
+      y[s] = 0.0; xold[s] = 0.0; invd[s] = 0.0; e0[s] = 0; rl[s] = 0;
+#pragma unroll
+      for (int q = 0; q < P; q++) { L[s][q] = 0.0; U[s][q] = 0.0; }
+      if (li < len) {
+         const int64_t r = r0 + li;
+         e0[s] = rowptr[r];
+         rl[s] = rowptr[r + 1] - e0[s];
+         y[s] = b[r];
+         xold[s] = (r < split) ? xa[r] : xb[r];
+         invd[s] = fac[(int64_t) P * n + r];
+         if (R32) invd[s] = (double) (float) invd[s];
+#pragma unroll
+         for (int q = 1; q <= P; q++) {
+            L[s][q - 1] = fac[(int64_t) (P - q) * n + r];
+            U[s][q - 1] = fac[(int64_t) (P + q) * n + r];
+            if (R32) { L[s][q - 1] = (double) (float) L[s][q - 1]; U[s][q - 1] = (double) (float) U[s][q - 1]; }
+         }
+      }
+   }
+   // residual of this lane's row(s): entries in stored order, GSW_UNROLL of them requested together (one round trip for the (column, value) pairs, one for the gathered x, whatever the row length up to 32)
+#pragma unroll
+   for (int s = 0; s < RPL; s++) {
+      double acc = 0.0;
+      for (int k0 = 0; __any (k0 < rl[s]); k0 += GSW_UNROLL) {
+         int cc[GSW_UNROLL];
+         VT vv[GSW_UNROLL];
+#pragma unroll
+         for (int u = 0; u < GSW_UNROLL; u++) {
+            const bool ok = k0 + u < rl[s];
+            cc[u] = ok ? colind[e0[s] + k0 + u] : 0;
+            vv[u] = ok ? val[e0[s] + k0 + u] : (VT) 0;
+         }
+         double xv[GSW_UNROLL];
+#pragma unroll
+         for (int u = 0; u < GSW_UNROLL; u++) xv[u] = (cc[u] < split) ? xa[cc[u]] : xb[cc[u]];
+#pragma unroll
+         for (int u = 0; u < GSW_UNROLL; u++)
+            if (k0 + u < rl[s]) acc += (double) vv[u] * xv[u];
+      }
+      if (s * NKP_WAVE + lane < len) y[s] -= acc;
+   }
+   // forward: y <- L^-1 y   (unit lower band)
+   for (int k = 0; k < len - 1; k++) {
+      const int ks = k >> 6, kl = k & (NKP_WAVE - 1);
+      double yk = 0.0;
+#pragma unroll
+      for (int s = 0; s < RPL; s++)
+         if (ks == s) yk = readlane_f64 (y[s], kl);
+#pragma unroll
+      for (int s = 0; s < RPL; s++) {
+         const int rel = s * NKP_WAVE + lane - k;
+#pragma unroll
+         for (int q = 1; q <= P; q++)
+            if (rel == q) y[s] -= L[s][q - 1] * yk;
+      }
+   }
+   // backward: y <- U^-1 y
+   for (int k = len - 1; k >= 0; k--) {
+      const int ks = k >> 6, kl = k & (NKP_WAVE - 1);
+      double xk = 0.0;
+#pragma unroll
+      for (int s = 0; s < RPL; s++)
+         if (ks == s) {
+            if (lane == kl) y[s] *= invd[s];
+            xk = readlane_f64 (y[s], kl);
+         }
+#pragma unroll
+      for (int s = 0; s < RPL; s++) {
+         const int rel = k - (s * NKP_WAVE + lane);
+#pragma unroll
+         for (int q = 1; q <= P; q++)
+            if (rel == q) y[s] -= U[s][q - 1] * xk;
+      }
+   }
+#pragma unroll
+   for (int s = 0; s < RPL; s++) {
+      const int li = s * NKP_WAVE + lane;
+      if (li < len) xout[(int64_t) r0 + li] = xold[s] + y[s];
+   }
+}
+
 // ---------------------------------------------------------------- launchers
 static inline dim3 cb_grid (int nblk) { return dim3 ((nblk + CB_WAVES - 1) / CB_WAVES); }
 
@@ -281,6 +390,25 @@ void launch_colblock_apply_range_r32 (const ColBlocksDev &B, int b0, int b1, con
 #undef R32_GO
 }
 
+// blocks [b0, b1) of one colour: xout_rows = x_rows + M^-1 (b - L x)_rows in one launch (gs_wave_kernel); r32: factors rounded
+// to f32 on load (the f32 storage mode of the cycle).  The level operator is read through L.valf when it has an f32 copy.
+void launch_gs_wave (const CsrDev &L, const ColBlocksDev &B, int b0, int b1, const double *xa, const double *xb, int split, const double *b, double *xout,
+                     int r32, hipStream_t st)
+{
+   if (b1 <= b0) return;
+   const int rpl = B.max_len <= NKP_WAVE ? 1 : 2;
+   const dim3 grid = cb_grid (b1 - b0);
+#define GSW_GO(PP, RR, VT_, R32_, VAL_) hipLaunchKernelGGL ((gs_wave_kernel<PP, RR, VT_, R32_>), grid, dim3 (CB_THREADS), 0, st, L.rowptr, L.colind, VAL_, \
+                                                              B.blk_start, b0, b1, B.n, B.fac, xa, xb, split, b, xout)
+#define GSW_PR(PP, RR) do { if (L.valf) { if (r32) GSW_GO (PP, RR, float, true, L.valf); else GSW_GO (PP, RR, float, false, L.valf); } \
+                            else { if (r32) GSW_GO (PP, RR, double, true, L.val); else GSW_GO (PP, RR, double, false, L.val); } } while (0)
+   if (B.P == 1) { if (rpl == 1) GSW_PR (1, 1); else GSW_PR (1, 2); }
+   else if (B.P == 2) { if (rpl == 1) GSW_PR (2, 1); else GSW_PR (2, 2); }
+   else { if (rpl == 1) GSW_PR (4, 1); else GSW_PR (4, 2); }
+#undef GSW_PR
+#undef GSW_GO
+}
+
 // ================================================================ lane-per-column apply
 // The wave-per-column substitution above is VALU-issue bound: 2*len dependent steps of
 // readlane + predicated FMA per column (rocprof: 137 us per half sweep at 1 degree against ~25 us
@@ -298,7 +426,7 @@ void launch_colblock_apply_range_r32 (const ColBlocksDev &B, int b0, int b1, con
 __global__ __launch_bounds__ (NKP_WAVE)
 void colblock_transpose_kernel (const int *__restrict__ blk_start, const int *__restrict__ grp_b0, const int *__restrict__ grp_nb,
                                 const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int ndiag, int64_t n,
-                                const double *__restrict__ fac, double *__restrict__ fac_t, int gw, float *__restrict__ fac_tf)
+                                const double *__restrict__ fac, double *__restrict__ fac_t, int gw, float *__restrict__ fac_tf, int pack)
 {
    const int g = blockIdx.x;
    const int lane = threadIdx.x;
@@ -311,8 +439,10 @@ void colblock_transpose_kernel (const int *__restrict__ blk_start, const int *__
       for (int k = 0; k < ml; k++)
       {
          const double v = (k < len) ? fac[(int64_t) d * n + r0 + k] : 0.0;
-         if (fac_tf) fac_tf[base + ((int64_t) d * ml + k) * gw + lane] = (float) v;
-         else fac_t[base + ((int64_t) d * ml + k) * gw + lane] = v;
+         // pack > 1 (colblock_apply_ldspack_kernel): `pack` consecutive steps of one column side by side, one 16-byte load
+         const int64_t at = pack > 1 ? base + (((int64_t) d * (ml / pack) + k / pack) * gw + lane) * pack + (k % pack) : base + ((int64_t) d * ml + k) * gw + lane;
+         if (fac_tf) fac_tf[at] = (float) v;
+         else fac_t[at] = v;
       }
 }
 
@@ -788,6 +918,197 @@ void colblock_apply_ldsres_kernel (const int *__restrict__ grp_nb, const int *__
       for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
 }
 
+// ================================================================ LDS-resident columns, factors packed along the column
+// What held the kernel above at 0.43 of the HBM peak (1 degree fine level: 27 us for 93 MB): a colour is ONE round of
+// waves (1468 groups of 32 columns on 256 CUs, 8 wave slots each), every wave walks its 2 x 4 factor chunks one behind
+// the other with a single chunk of look-ahead, and a chunk is 32-48 load instructions of 128 bytes -- the 63 loads a
+// wave may have in flight are 8 KB.  A latency-bound chain per wave with nothing to overlap it.
+// Here the factors of 4 consecutive steps of a column sit side by side ([diag][k / 4][lane][4], f32), so one instruction
+// moves 512 bytes and a chunk of 16 steps is 2-3 instructions per diagonal; and the schedule is static: every forward chunk
+// is requested before the right-hand side is even staged, the backward chunks follow as the registers of consumed forward
+// chunks come free (a compile-time budget of LDSP_BUDGET registers decides what is in flight when), so by the time the
+// forward sweep is done the backward factors have landed.  Same operations in the same order => same bits.
+#define LDSP_BUDGET 200
+
+template <int NCH, int FR, int BR>
+struct LdspSchedule {
+   int f_upfront = 0, b_upfront = 0;
+   int f_after[NCH] = {}, b_after_f[NCH] = {}, b_after_b[NCH] = {};     // chunks issued in total once fwd step c / bwd step j is done
+   constexpr LdspSchedule ()
+   {
+      int fi = 0, bi = 0, fc = 0, bc = 0;
+      while (fi < NCH && ((fi - fc) * FR + (bi - bc) * BR + FR <= LDSP_BUDGET || fi == fc)) fi++;
+      while (bi < NCH && (fi - fc) * FR + (bi - bc) * BR + BR <= LDSP_BUDGET) bi++;
+      f_upfront = fi;
+      b_upfront = bi;
+      for (int c = 0; c < NCH; c++) {
+         fc++;
+         while (fi < NCH && ((fi - fc) * FR + (bi - bc) * BR + FR <= LDSP_BUDGET || fi == fc)) fi++;
+         while (bi < NCH && ((fi - fc) * FR + (bi - bc) * BR + BR <= LDSP_BUDGET || (fc == NCH && bi == bc))) bi++;
+         f_after[c] = fi;
+         b_after_f[c] = bi;
+      }
+      for (int j = 0; j < NCH; j++) {
+         bc++;
+         while (bi < NCH && ((bi - bc) * BR + BR <= LDSP_BUDGET || bi == bc)) bi++;
+         b_after_b[j] = bi;
+      }
+   }
+};
+
+// a chunk of 16 steps as it comes off the loads: one float4 per diagonal and 4 steps
+template <int P>
+struct PackChunk { float4 q[P + 1][4]; };
+
+// keeps a loaded float4 as it is until this point of the program: without it the compiler converts every factor to f64
+// right behind its load (twice the registers, and a wait for the load where it was meant to stay in flight)
+__device__ __forceinline__ void ldsp_pin (float4 &v) { asm volatile ("" : "+v" (v.x), "+v" (v.y), "+v" (v.z), "+v" (v.w)); }
+
+template <int P>
+__device__ __forceinline__ void ldsp_load_fwd (PackChunk<P> &c, const float4 *__restrict__ f4, int mlq, int k0, int gw)
+{
+#pragma unroll
+   for (int q = 1; q <= P; q++)
+#pragma unroll
+      for (int j4 = 0; j4 < 4; j4++) c.q[q - 1][j4] = f4[((int64_t) (P - q) * mlq + (k0 >> 2) + j4) * gw];
+}
+
+template <int P>
+__device__ __forceinline__ void ldsp_load_bwd (PackChunk<P> &c, const float4 *__restrict__ f4, int mlq, int k0, int gw)
+{
+#pragma unroll
+   for (int q = 0; q <= P; q++)
+#pragma unroll
+      for (int j4 = 0; j4 < 4; j4++) c.q[q][j4] = f4[((int64_t) (P + q) * mlq + (k0 >> 2) + j4) * gw];
+}
+
+__device__ __forceinline__ float ldsp_elem (const float4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+// steps k0 .. k0 + 15 of the forward substitution (step_fwd above, factors taken from the packed chunk)
+template <int P>
+__device__ __forceinline__ void ldsp_step_fwd (PackChunk<P> &c, double *lds, int s, int len, int k0, double (&w)[P])
+{
+   double b[16];
+#pragma unroll
+   for (int j = 0; j < 16; j++) b[j] = (k0 + j < len) ? lds[LDS_PAD (s + k0 + j)] : 0.0;
+#pragma unroll
+   for (int j4 = 0; j4 < 4; j4++) {
+#pragma unroll
+      for (int q = 0; q < P; q++) ldsp_pin (c.q[q][j4]);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+         const int j = 4 * j4 + i;
+         double y = b[j];
+#pragma unroll
+         for (int q = P; q >= 1; q--)
+            if (k0 + j - q >= 0) y -= (double) ldsp_elem (c.q[q - 1][j4], i) * w[q - 1];
+#pragma unroll
+         for (int q = P - 1; q >= 1; q--) w[q] = w[q - 1];
+         w[0] = y;
+         if (k0 + j < len) lds[LDS_PAD (s + k0 + j)] = y;
+      }
+   }
+}
+
+// steps k0 + 15 .. k0 of the back substitution (step_bwd above)
+template <int P>
+__device__ __forceinline__ void ldsp_step_bwd (PackChunk<P> &c, double *lds, int s, int len, int k0, double (&u)[P])
+{
+   double y[16];
+#pragma unroll
+   for (int j = 0; j < 16; j++) y[j] = (k0 + j < len) ? lds[LDS_PAD (s + k0 + j)] : 0.0;
+#pragma unroll
+   for (int j4 = 3; j4 >= 0; j4--) {
+#pragma unroll
+      for (int q = 0; q <= P; q++) ldsp_pin (c.q[q][j4]);
+#pragma unroll
+      for (int i = 3; i >= 0; i--) {
+         const int j = 4 * j4 + i;
+         double x = y[j];
+#pragma unroll
+         for (int q = P; q >= 1; q--) x -= (double) ldsp_elem (c.q[q][j4], i) * u[q - 1];
+         x *= (double) ldsp_elem (c.q[0][j4], i);
+#pragma unroll
+         for (int q = P - 1; q >= 1; q--) u[q] = u[q - 1];
+         u[0] = x;
+         if (k0 + j < len) lds[LDS_PAD (s + k0 + j)] = x;
+      }
+   }
+}
+
+template <int P, int NCH>
+__global__ __launch_bounds__ (NKP_WAVE, 2)
+void colblock_apply_ldspack_kernel (const int *__restrict__ grp_nb, const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
+                                    const float *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
+                                    const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp)
+{
+   extern __shared__ double lds[];            // the group's right-hand side, then its solution
+   constexpr int gw = 32, CH = 16;
+   constexpr LdspSchedule<NCH, P * CH, (P + 1) * CH> S;
+   const int g = blockIdx.x + g_first;
+   const int lane = threadIdx.x;
+   const int nb = grp_nb[g], ml = grp_maxlen[g];            // ml is a multiple of 16, at most NCH * 16
+   const int nch = ml / CH, mlq = ml >> 2;
+   const int R0 = grp_row0[g], nrows = grp_row0[ngrp + g];
+   // lanes >= 32 own no column: they help to stage the right-hand side, and their (unused) factor loads repeat lane - 32's
+   const int cl = lane & (gw - 1);
+   int s = 0, len = 0;
+   if (lane < gw) { s = col_slot[g * gw + lane]; len = col_slot[(ngrp + g) * gw + lane]; }
+   const float4 *f4 = reinterpret_cast<const float4 *> (fac_t + grp_base[g]) + cl;
+   // The loads are unconditional so that the whole kernel is one straight line the static schedule can be written into: a
+   // group with fewer than NCH chunks requests its last chunk again (an L2 hit) and skips the steps.
+   // F[c] = forward chunk min (c, nch - 1);  Bq[j] = backward chunk max (nch - 1 - j, 0)
+#define LDSP_FWD_K0(t) (((t) < nch ? (t) : nch - 1) * CH)
+#define LDSP_BWD_K0(t) ((nch - 1 - (t) > 0 ? nch - 1 - (t) : 0) * CH)
+   PackChunk<P> F[NCH], Bq[NCH];
+#pragma unroll
+   for (int t = 0; t < NCH; t++)
+      if (t < S.f_upfront) ldsp_load_fwd<P> (F[t], f4, mlq, LDSP_FWD_K0 (t), gw);
+#pragma unroll
+   for (int t = 0; t < NCH; t++)
+      if (t < S.b_upfront) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+   for (int i0 = lane; i0 < nrows; i0 += 8 * NKP_WAVE) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = (i0 + u * NKP_WAVE < nrows) ? rhs[(int64_t) R0 + i0 + u * NKP_WAVE] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+         if (i0 + u * NKP_WAVE < nrows) lds[LDS_PAD (i0 + u * NKP_WAVE)] = t[u];
+   }
+   __syncthreads ();
+   // every lane walks the schedule (idle lanes on zero-length columns: no LDS traffic), so there is no divergent region
+   if (lane >= nb) len = 0;
+   double w[P];
+#pragma unroll
+   for (int q = 0; q < P; q++) w[q] = 0.0;
+#pragma unroll
+   for (int c = 0; c < NCH; c++) {
+      if (c < nch) ldsp_step_fwd<P> (F[c], lds, s, len, c * CH, w);
+#pragma unroll
+      for (int t = 0; t < NCH; t++)
+         if (t >= (c ? S.f_after[c - 1] : S.f_upfront) && t < S.f_after[c]) ldsp_load_fwd<P> (F[t], f4, mlq, LDSP_FWD_K0 (t), gw);
+#pragma unroll
+      for (int t = 0; t < NCH; t++)
+         if (t >= (c ? S.b_after_f[c - 1] : S.b_upfront) && t < S.b_after_f[c]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+   }
+#pragma unroll
+   for (int q = 0; q < P; q++) w[q] = 0.0;
+#pragma unroll
+   for (int j = 0; j < NCH; j++) {
+      if (j < nch) ldsp_step_bwd<P> (Bq[j], lds, s, len, (nch - 1 - j) * CH, w);
+#pragma unroll
+      for (int t = 0; t < NCH; t++)
+         if (t >= (j ? S.b_after_b[j - 1] : S.b_after_f[NCH - 1]) && t < S.b_after_b[j]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+   }
+#undef LDSP_FWD_K0
+#undef LDSP_BWD_K0
+   __syncthreads ();
+   if (accumulate)
+      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] += lds[LDS_PAD (i)];
+   else
+      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
+}
+
 template <class T>
 static int up (T **dst, const std::vector<T> &src, size_t *bytes)
 {
@@ -838,6 +1159,9 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       const int min_long = env_min ? min_cols : 8000, min_short = env_min ? min_cols : 20000;
       B.ldsres = lr > 0 && on && B.max_len <= 128 && ((B.max_len > 64 && ncols >= min_long) || (lr == 2 && ncols >= min_short));
       if (B.ldsres) { B.stream = 0; gw = 32; }
+      // 2 = factors packed four steps to a 16-byte load (colblock_apply_ldspack_kernel): f32 storage, at most 5 chunks of 16
+      // levels; the fused half sweep and the tail kernel read the plain layout
+      if (B.ldsres && f32 && B.max_len <= 80 && T.col_ldsres_packed && !h_rowptr && T.ml_tail_rows <= 0) B.ldsres = 2;
    }
    while (!B.stream && !B.ldsres && gw > 8 && (size_t) ((2 * B.P + 2) * ((B.max_len + 7) & ~7) * gw) * sizeof (double) > 56 * 1024) gw >>= 1;
    B.gw = gw;
@@ -908,7 +1232,7 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
    *device_bytes += (size_t) total * fsz;
    if (B.ngrp)
       hipLaunchKernelGGL (colblock_transpose_kernel, dim3 (B.ngrp), dim3 (NKP_WAVE), 0, st, B.blk_start, B.grp_b0, B.grp_nb, B.grp_maxlen,
-                          B.grp_base, ndiag, B.n, B.fac, B.fac_t, gw, B.fac_tf);
+                          B.grp_base, ndiag, B.n, B.fac, B.fac_t, gw, B.fac_tf, B.ldsres == 2 ? 4 : 1);
    if (gs_ok) {
       const int gs_bytes = (GS_NNZ + lds_need) * (int) sizeof (double);
       if (gs_bytes > 64 * 1024) gs_ok = false;          // not worth running one workgroup per CU
@@ -941,6 +1265,11 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       (void) hipFuncSetAttribute ((const void *) colblock_apply_ldsres_kernel<PP, float, NKP_LDSRES_CH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);  \
       (void) hipFuncSetAttribute ((const void *) colblock_apply_ldsres_kernel<PP, double, NKP_LDSRES_CH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
       (void) hipFuncSetAttribute ((const void *) colblock_apply_ldsres_kernel<PP, float, NKP_LDSRES_CH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
+      LDS_OPT_IN (1); LDS_OPT_IN (2); LDS_OPT_IN (4);
+#undef LDS_OPT_IN
+#define LDS_OPT_IN(PP)                                                                                                                    \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_ldspack_kernel<PP, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+      (void) hipFuncSetAttribute ((const void *) colblock_apply_ldspack_kernel<PP, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)
       LDS_OPT_IN (1); LDS_OPT_IN (2); LDS_OPT_IN (4);
 #undef LDS_OPT_IN
    }
@@ -1262,6 +1591,17 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
                                   B.fac_tf, r, z, accumulate, B.rhs_slots, B.grp_row0, B.col_slot, B.ngrp);
          return;
       }
+   }
+   if (B.ldsres == 2) {
+#define LDSP_LAUNCH(PP) do { if (B.max_len <= 64) hipLaunchKernelGGL ((colblock_apply_ldspack_kernel<PP, 4>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.grp_nb, B.grp_maxlen, \
+                                                                        B.grp_base, g0, B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp);                                \
+                             else hipLaunchKernelGGL ((colblock_apply_ldspack_kernel<PP, 5>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.grp_nb, B.grp_maxlen,                      \
+                                                      B.grp_base, g0, B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp); } while (0)
+      if (B.P == 1) LDSP_LAUNCH (1);
+      else if (B.P == 2) LDSP_LAUNCH (2);
+      else LDSP_LAUNCH (4);
+#undef LDSP_LAUNCH
+      return;
    }
    if (B.ldsres) {
 #define LDSRES_LAUNCH2(PP, EE)                                                                                                                                    \

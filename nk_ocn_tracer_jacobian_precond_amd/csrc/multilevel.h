@@ -13,6 +13,7 @@ struct MlLevel {
    int color_grp[3] = { 0, 0, 0 };   // lane-per-column groups of colour c
    int64_t rows0 = 0;           // rows of colour 0 (they come first)
    int wave_columns = 0;        // few columns: solve them one per wave (colblock_apply_kernel) instead of one per lane
+   int wave_fused = 0;          // ... and run every half sweep as one launch (gs_wave_kernel: residual rows + band solve per wave)
    int64_t nc = 0;              // rows of the next coarser level
    int *cmap = nullptr;         // fine row -> coarse row                 (prolongation)
    int *rptr = nullptr, *ridx = nullptr;   // coarse row -> its fine rows (restriction)

@@ -1012,6 +1012,10 @@ int finish_level_columns (MlHierarchy &H, MlLevel &V, int l, const std::vector<i
       const int lrc = colblock_build_lane_layout (V.B, pblk.data (), ranges, 2, V.color_grp, &H.device_bytes, st, H.f32, H.fused ? h_prow : nullptr);
       if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
       V.wave_columns = ncol <= H.tune->col_wave_max && V.B.dropped == 0;
+      // ... and their half sweeps are one launch each (residual of the column's rows + its band solve, gs_wave_kernel)
+      V.wave_fused = V.wave_columns && H.tune->ml_wave_fused != 0;
+      // the block-per-group fused kernel serves matching storage only (f32 operator with f32 factors, or f64 with f64)
+      if (V.B.gs_ok && !((V.B.fac_tf && V.L.valf) || (V.B.fac_t && !V.L.valf))) V.B.gs_ok = 0;
       T.lay += secs_since (t_lay0);
    }
    // f32 storage mode: the f64 copy of the level operator was only needed to factor the column blocks
@@ -1500,7 +1504,9 @@ static void gs_half (const MlHierarchy &H, MlLevel &V, int c, bool fused, hipStr
    if (fused) {
       const int out = (V.cur[0] != V.cur[1]) ? V.cur[1 - c] : 1 - V.cur[c];
       const int rows0 = (int) V.rows0;
-      launch_gs_fused (V.L, V.B, V.color_grp[c], V.color_grp[c + 1], V.xbuf (V.cur[0]), V.xbuf (V.cur[1]), rows0, V.b, V.xbuf (out), st);
+      // (the launchers cannot refuse: ml_setup clears gs_ok / wave_fused for a level whose storage they do not serve)
+      if (V.wave_fused) launch_gs_wave (V.L, V.B, V.color_blk[c], V.color_blk[c + 1], V.xbuf (V.cur[0]), V.xbuf (V.cur[1]), rows0, V.b, V.xbuf (out), H.f32, st);
+      else (void) launch_gs_fused (V.L, V.B, V.color_grp[c], V.color_grp[c + 1], V.xbuf (V.cur[0]), V.xbuf (V.cur[1]), rows0, V.b, V.xbuf (out), st);
       V.cur[c] = out;
       return;
    }
@@ -1533,13 +1539,14 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
    }
    // ml_fused_max_cols: the fused half sweep only on levels with at most that many columns (the launch-bound end)
    const int fused_max = H.tune->ml_fused_max_cols;
-   const bool fused = H.fused && V.B.gs_ok && (fused_max <= 0 || V.color_grp[2] * V.B.gw <= fused_max);
+   const bool fused = V.wave_fused || (H.fused && V.B.gs_ok && (fused_max <= 0 || V.color_grp[2] * V.B.gw <= fused_max));
    // pre-smoothing from x = 0: the first half-sweep needs no SpMV (r = b on colour 0)
    launch_fill (V.x, 0.0, V.n, st);
    if (fused) {
       // colour 0's first values go to the second buffer: the level starts incoherent, and the odd number of fused half
       // sweeps that follows (colour 1, then nu - 1 full sweeps) ends coherent
-      launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.b, V.x2, 0, st);
+      if (V.wave_fused) column_solves (H, V, 0, V.b, V.x2, 0, st);
+      else launch_colblock_apply_lanes (V.B, V.color_grp[0], V.color_grp[1], V.b, V.x2, 0, st);
       V.cur[0] = 1;
       gs_half (H, V, 1, true, st);
    } else {

@@ -80,7 +80,8 @@ struct ColBlocksDev {
    int rhs_slots = 0;          // LDS doubles reserved for the staged right-hand side
    // fused Gauss-Seidel half sweep (gs_fused_kernel): row blocks of every group's rows
    int stream = 0;             // 1: 64 columns per wave, factors read straight from HBM (colblock_apply_stream_kernel)
-   int ldsres = 0;             // 1: 32 columns per wave, factors streamed, the column resident in LDS (colblock_apply_ldsres_kernel)
+   int ldsres = 0;             // 1: 32 columns per wave, factors streamed, the column resident in LDS (colblock_apply_ldsres_kernel);
+                               // 2: the same with the factors packed four steps to a load and a static prefetch schedule (colblock_apply_ldspack_kernel)
    int gs_ok = 0;              // 1 if the level can run it (no row longer than GS_NNZ, LDS need within 64 KB)
    int gs_lds_bytes = 0;
    int *gs_rb_ptr = nullptr;   // [ngrp+1] first row-block boundary of the group
@@ -113,6 +114,10 @@ void launch_colblock_apply (const ColBlocksDev &B, const double *r, double *z, h
 // blocks [b0, b1) only; accumulate: z_blk += M_blk^-1 r_blk, else z_blk = M_blk^-1 r_blk
 void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, hipStream_t st);
 void launch_colblock_apply_range_r32 (const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, hipStream_t st);
+// blocks [b0, b1) of one colour in ONE launch, one column per wave: xout_rows = x_rows + M_blk^-1 (b - L x)_rows, x taken from
+// xa (rows < split) and xb (the others); r32 as above
+void launch_gs_wave (const CsrDev &L, const ColBlocksDev &B, int b0, int b1, const double *xa, const double *xb, int split, const double *b, double *xout,
+                     int r32, hipStream_t st);
 
 // ---------------------------------------------------------------- BLAS-1 style kernels
 #define NKP_RED_BLOCKS 1024        // partial sums per reduction (fixed => deterministic)

@@ -82,9 +82,9 @@ static void builtin_tuning (nkp_tuning *t)
    t->ml_split = 1; t->ml_pocket = 4; t->ml_big_from = -3; t->ml_coarsest_rows = 3000; t->ml_dense_max = 6000;
    t->ml_theta = 0.0; t->ml_tau = 0.01; t->ml_device_min = 100000;
    t->ml_smooth_coarse = 0; t->ml_coarse_from = 2; t->ml_gamma_from = 0; t->ml_gamma_to = 0; t->ml_f32 = 1; t->ml_host_inverse = 0;
-   t->ml_fused = 0; t->ml_fused_max_cols = 0; t->ml_coarsest_sweeps = 30; t->ml_tail_rows = 0; t->ml_omega = 1.1;
+   t->ml_fused = 0; t->ml_fused_max_cols = 0; t->ml_wave_fused = 1; t->ml_coarsest_sweeps = 30; t->ml_tail_rows = 0; t->ml_omega = 1.1;
    t->col_ldsres = 2; t->col_stream = 1; t->col_stream_min = -1; t->col_stream_gw = 32; t->col_wave_max = 8192; t->col_w3 = 1;
-   t->col_group = 8; t->col_pipe_min = 0; t->col_ldsres_early = 0;
+   t->col_group = 8; t->col_pipe_min = 0; t->col_ldsres_early = 0; t->col_ldsres_packed = 1;
    t->spmv_variant = 4; t->spmv_compress = 0; t->spmv_pipe_min = 1024; t->spmv_run = 1; t->spmv_wgs = 256;
    t->precond_steps = 0; t->equil = -1; t->dist_overlap = 1; t->dist_ras = 1; t->force_dist = 0; t->setup_threads = 0; t->plan_times = 0;
    t->ml_drop_intertracer = 0;
@@ -112,13 +112,13 @@ extern "C" int nkp_default_tuning (nkp_tuning *t)
    ENV_POS ("NKP_ML_SMOOTH_COARSE", ml_smooth_coarse); ENV_POS ("NKP_ML_COARSE_FROM", ml_coarse_from);
    ENV_INT ("NKP_ML_GAMMA_FROM", ml_gamma_from); ENV_INT ("NKP_ML_GAMMA_TO", ml_gamma_to);
    ENV_FLAG ("NKP_ML_F32", ml_f32); ENV_FLAG ("NKP_ML_HOST_INVERSE", ml_host_inverse); ENV_FLAG ("NKP_ML_FUSED", ml_fused);
-   ENV_INT ("NKP_ML_FUSED_MAX_COLS", ml_fused_max_cols); ENV_POS ("NKP_ML_COARSEST_SWEEPS", ml_coarsest_sweeps);
+   ENV_INT ("NKP_ML_FUSED_MAX_COLS", ml_fused_max_cols); ENV_FLAG ("NKP_ML_WAVE_FUSED", ml_wave_fused); ENV_POS ("NKP_ML_COARSEST_SWEEPS", ml_coarsest_sweeps);
    if ((e = getenv ("NKP_ML_TAIL_ROWS")) && *e) t->ml_tail_rows = atoll (e);
    if ((e = getenv ("NKP_ML_OMEGA")) && atof (e) > 0.0) t->ml_omega = atof (e);
    ENV_INT ("NKP_COL_LDSRES", col_ldsres); ENV_FLAG ("NKP_COLSTREAM", col_stream); ENV_INT ("NKP_COLSTREAM_MIN", col_stream_min);
    if ((e = getenv ("NKP_COLSTREAM_GW")) && *e) t->col_stream_gw = atoi (e) == 64 ? 64 : 32;
    ENV_INT ("NKP_COLWAVE_MAX", col_wave_max); ENV_FLAG ("NKP_COL_W3", col_w3); ENV_INT ("NKP_COLGROUP", col_group);
-   ENV_INT ("NKP_COLPIPE_MIN", col_pipe_min); ENV_FLAG ("NKP_LDSRES_EARLY", col_ldsres_early);
+   ENV_INT ("NKP_COLPIPE_MIN", col_pipe_min); ENV_FLAG ("NKP_LDSRES_EARLY", col_ldsres_early); ENV_FLAG ("NKP_COL_PACKED", col_ldsres_packed);
    ENV_INT ("NKP_SPMV_VARIANT", spmv_variant); ENV_FLAG ("NKP_SPMV_COMPRESS", spmv_compress); ENV_INT ("NKP_SPMV_PIPE_MIN", spmv_pipe_min);
    ENV_POS ("NKP_SPMV_RUN", spmv_run); ENV_POS ("NKP_SPMV_WGS", spmv_wgs);
    ENV_POS ("NKP_PRECOND_STEPS", precond_steps); ENV_FLAG ("NKP_EQUIL", equil);

@@ -49,10 +49,10 @@ class NkpTuning(C.Structure):
         ("struct_size", C.c_int), ("ml_split", C.c_int), ("ml_pocket", C.c_int), ("ml_big_from", C.c_int), ("ml_coarsest_rows", C.c_int),
         ("ml_dense_max", C.c_int), ("ml_theta", C.c_double), ("ml_tau", C.c_double), ("ml_device_min", C.c_int64),
         ("ml_smooth_coarse", C.c_int), ("ml_coarse_from", C.c_int), ("ml_gamma_from", C.c_int), ("ml_gamma_to", C.c_int), ("ml_f32", C.c_int),
-        ("ml_host_inverse", C.c_int), ("ml_fused", C.c_int), ("ml_fused_max_cols", C.c_int), ("ml_coarsest_sweeps", C.c_int),
+        ("ml_host_inverse", C.c_int), ("ml_fused", C.c_int), ("ml_fused_max_cols", C.c_int), ("ml_wave_fused", C.c_int), ("ml_coarsest_sweeps", C.c_int),
         ("ml_tail_rows", C.c_int64), ("ml_omega", C.c_double),
         ("col_ldsres", C.c_int), ("col_stream", C.c_int), ("col_stream_min", C.c_int), ("col_stream_gw", C.c_int), ("col_wave_max", C.c_int),
-        ("col_w3", C.c_int), ("col_group", C.c_int), ("col_pipe_min", C.c_int), ("col_ldsres_early", C.c_int),
+        ("col_w3", C.c_int), ("col_group", C.c_int), ("col_pipe_min", C.c_int), ("col_ldsres_early", C.c_int), ("col_ldsres_packed", C.c_int),
         ("spmv_variant", C.c_int), ("spmv_compress", C.c_int), ("spmv_pipe_min", C.c_int), ("spmv_run", C.c_int), ("spmv_wgs", C.c_int),
         ("precond_steps", C.c_int), ("equil", C.c_int), ("dist_overlap", C.c_int), ("dist_ras", C.c_int), ("force_dist", C.c_int),
         ("setup_threads", C.c_int), ("plan_times", C.c_int), ("ml_drop_intertracer", C.c_int),

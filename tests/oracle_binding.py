@@ -147,6 +147,10 @@ def rowblock_partition(n, nprocs, rank):
     return a.value, b.value
 
 
+def set_num_threads(t):
+    lib().ora_set_num_threads(int(t))
+
+
 def num_threads():
     return lib().ora_num_threads()
 

@@ -659,6 +659,9 @@ def test_column_stream_kernel_is_bit_identical(case, medium, monkeypatch):
     elif case == "long_columns":
         p = synth.generate(imt=24, jmt=20, km=70, adv="centred", hmix="const", seed=5)
         blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    elif case == "km80":
+        p = synth.generate(imt=30, jmt=24, km=80, adv="upwind3", hmix="isop", seed=7)       # 5 chunks of 16 levels, band of 2
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
     else:
         p = synth.generate(imt=30, jmt=24, km=20, adv="upwind3", hmix="isop", seed=6)       # upwind3: in-column band of 2
         blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
@@ -687,6 +690,9 @@ def test_column_lds_resident_kernel_is_bit_identical(case, medium, monkeypatch):
     elif case == "long_columns":
         p = synth.generate(imt=24, jmt=20, km=70, adv="centred", hmix="const", seed=5)
         blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    elif case == "km80":
+        p = synth.generate(imt=30, jmt=24, km=80, adv="upwind3", hmix="isop", seed=7)       # 5 chunks of 16 levels, band of 2
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
     else:
         p = synth.generate(imt=30, jmt=24, km=20, adv="upwind3", hmix="isop", seed=6)       # upwind3: in-column band of 2
         blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
@@ -698,13 +704,17 @@ def test_column_lds_resident_kernel_is_bit_identical(case, medium, monkeypatch):
         monkeypatch.setenv("NKP_ML_F32", f32)
         for precond, kw in ((solver.PRECOND_COLUMN_JACOBI, {}), (solver.PRECOND_MULTILEVEL, dict(col_i=ci, col_j=cj))):
             z = {}
-            for variant, (stream, ldsres) in (("lanes", ("0", "0")), ("ldsres", ("1", "2"))):
+            # "packed" (round 3, f32 factors and columns of at most 80 levels only): the factors of four consecutive steps side by
+            # side, one 16-byte load, and a static prefetch schedule (colblock_apply_ldspack_kernel)
+            for variant, (stream, ldsres, packed) in (("lanes", ("0", "0", "0")), ("ldsres", ("1", "2", "0")), ("packed", ("1", "2", "1"))):
                 monkeypatch.setenv("NKP_COLSTREAM", stream)
                 monkeypatch.setenv("NKP_COL_LDSRES", ldsres)
+                monkeypatch.setenv("NKP_COL_PACKED", packed)
                 with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, precond=precond, restart=4, **kw) as s:
                     z[variant] = s.precond_apply(r)
-            assert np.isfinite(z["ldsres"]).all()
+            assert np.isfinite(z["ldsres"]).all() and np.isfinite(z["packed"]).all()
             assert np.array_equal(z["lanes"], z["ldsres"]), (case, f32, precond, np.abs(z["lanes"] - z["ldsres"]).max())
+            assert np.array_equal(z["lanes"], z["packed"]), (case, f32, precond, np.abs(z["lanes"] - z["packed"]).max())
 
 
 @pytest.mark.parametrize("case", ["medium", "long_columns", "tracers2"])
@@ -726,11 +736,16 @@ def test_wave_per_column_on_small_levels_is_bit_identical(case, medium, monkeypa
     for f32 in ("1", "0"):
         monkeypatch.setenv("NKP_ML_F32", f32)
         z = {}
-        for wmax in ("0", "1000000"):
+        # lane-per-column kernels everywhere | one column per wave, two launches per half sweep | the same in ONE launch per half
+        # sweep (gs_wave_kernel: the wave computes the residual of its column's rows itself, x ping-ponged between two buffers)
+        for wmax, fused in (("0", "1"), ("1000000", "0"), ("1000000", "1")):
             monkeypatch.setenv("NKP_COLWAVE_MAX", wmax)
+            monkeypatch.setenv("NKP_ML_WAVE_FUSED", fused)
             with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, coupled_tracer_cnt=cnt, restart=4) as s:
-                z[wmax] = s.precond_apply(r)
-        assert np.array_equal(z["0"], z["1000000"]), (case, f32, np.abs(z["0"] - z["1000000"]).max())
+                z[wmax, fused] = s.precond_apply(r)
+        assert np.isfinite(z["1000000", "1"]).all()
+        assert np.array_equal(z["0", "1"], z["1000000", "0"]), (case, f32, np.abs(z["0", "1"] - z["1000000", "0"]).max())
+        assert np.array_equal(z["0", "1"], z["1000000", "1"]), (case, f32, np.abs(z["0", "1"] - z["1000000", "1"]).max())
 
 
 def test_device_dense_inverse_matches_host(medium, monkeypatch):
