@@ -23,6 +23,7 @@
 #include <string>
 #include <sys/stat.h>
 #include <thread>
+#include <algorithm>
 #include <vector>
 #include <time.h>
 #include <unistd.h>
@@ -236,8 +237,17 @@ int main (int argc, char *argv[])
       printf ("(%d) inout_fname        = %s\n\n", iam, inout_fname);
    }
 
+#ifdef NKP_DIST
+   // several ranks: every rank reads the row pointers and, once it knows its rows, only THEIR entries (hyperslab reads; the
+   // reference has rank 0 read the whole matrix and send slices, src/solve_ABdist.c:141-225) -- at 0.25 degree the whole
+   // matrix is 11 GB per rank
+   const bool sliced = world > 1;
+   if (sliced ? get_sparse_matrix_header (matrix_fname) : get_sparse_matrix (matrix_fname))
+      exit (EXIT_FAILURE);
+#else
    if (get_sparse_matrix (matrix_fname))
       exit (EXIT_FAILURE);
+#endif
    if (dbg_lvl)
       printf ("(%d) row-oriented matrix read in\n", iam);
    // index maps before setup: the water-column boundaries come from them
@@ -400,7 +410,31 @@ int main (int argc, char *argv[])
          fprintf (stderr, "(%d) malloc failed in %s for the local row block\n", iam, argv[0]);
          exit (EXIT_FAILURE);
       }
-      if (nkp_permuted_rows (flat_len, rowptr, colind, nzval_row_wise, cm_perm, inv, fst_row, fst_row + m_loc, rowptr_loc, colind_loc, val_loc)) {
+      if (sliced) {
+         // the band's rows are `coupled_tracer_cnt` contiguous runs of the file (one per tracer): read those, then permute
+         const int tsl = flat_len / coupled_tracer_cnt;
+         const int lo0 = blk_start[fst_cell], hi0 = blk_start[fst_cell + ncell_loc];       // the band within tracer 0
+         std::vector<size_t> ebase ((size_t) coupled_tracer_cnt + 1, 0);
+         for (int t = 0; t < coupled_tracer_cnt; t++) ebase[(size_t) t + 1] = ebase[(size_t) t] + (size_t) (rowptr[t * tsl + hi0] - rowptr[t * tsl + lo0]);
+         std::vector<int_t> col_c (ebase.back () + 1);
+         std::vector<double> val_c (ebase.back () + 1);
+         for (int t = 0; t < coupled_tracer_cnt; t++)
+            if (get_sparse_matrix_rows (matrix_fname, t * tsl + lo0, t * tsl + hi0, col_c.data () + ebase[(size_t) t], val_c.data () + ebase[(size_t) t]))
+               exit (EXIT_FAILURE);
+         std::vector<std::pair<int_t, double>> buf;
+         rowptr_loc[0] = 0;
+         for (int r = 0; r < m_loc; r++) {
+            const int old = cm_perm[fst_row + r], t = old / tsl;
+            const size_t src = ebase[(size_t) t] + (size_t) (rowptr[old] - rowptr[t * tsl + lo0]);
+            const int len = rowptr[old + 1] - rowptr[old];
+            buf.clear ();
+            for (int e = 0; e < len; e++) buf.push_back ({ inv[col_c[src + (size_t) e]], val_c[src + (size_t) e] });
+            std::sort (buf.begin (), buf.end (), [] (const std::pair<int_t, double> &x, const std::pair<int_t, double> &y) { return x.first < y.first; });
+            int_t o = rowptr_loc[r];
+            for (const auto &pr : buf) { colind_loc[o] = pr.first; val_loc[o] = pr.second; o++; }
+            rowptr_loc[r + 1] = o;
+         }
+      } else if (nkp_permuted_rows (flat_len, rowptr, colind, nzval_row_wise, cm_perm, inv, fst_row, fst_row + m_loc, rowptr_loc, colind_loc, val_loc)) {
          fprintf (stderr, "(%d) %s\n", iam, nkp_last_error ());
          exit (EXIT_FAILURE);
       }
@@ -428,7 +462,22 @@ int main (int argc, char *argv[])
       opt.col_j = col_j + fst_blk;
       if (dbg_lvl > 1)
          printf ("(%d) fst_row, flat_len_loc, nnz_loc = %d, %d, %d\n", iam, fst_row, m_loc, rowptr_loc[m_loc]);
-      info = nkp_create_dist (&solver, &opt, flat_len, fst_row, m_loc, rowptr_loc[m_loc], rowptr_loc, colind + e0, nzval_row_wise + e0,
+      const int_t *colind_use = colind ? colind + e0 : NULL;
+      const double *val_use = nzval_row_wise ? nzval_row_wise + e0 : NULL;
+      std::vector<int_t> col_own;
+      std::vector<double> val_own;
+      if (sliced) {
+         // this rank's colind / nzval slice, straight from the file (src/solve_ABdist.c:188-225 sends the same slices from rank 0)
+         col_own.resize ((size_t) rowptr_loc[m_loc] + 1);
+         val_own.resize ((size_t) rowptr_loc[m_loc] + 1);
+         if (get_sparse_matrix_rows (matrix_fname, fst_row, fst_row + m_loc, col_own.data (), val_own.data ()))
+            exit (EXIT_FAILURE);
+         colind_use = col_own.data ();
+         val_use = val_own.data ();
+         if (dbg_lvl)
+            printf ("(%d) read rows %d..%d of the matrix: %d of %d entries\n", iam, fst_row, fst_row + m_loc, rowptr_loc[m_loc], nnz);
+      }
+      info = nkp_create_dist (&solver, &opt, flat_len, fst_row, m_loc, rowptr_loc[m_loc], rowptr_loc, colind_use, val_use,
                               blk_loc, nblk_loc, coupled_tracer_cnt, use_comm ? &ops : NULL);
       free (rowptr_loc);
       free (blk_loc);

@@ -984,13 +984,13 @@ __device__ __forceinline__ void ldsp_load_bwd (PackChunk<P> &c, const float4 *__
 
 __device__ __forceinline__ float ldsp_elem (const float4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
-// steps k0 .. k0 + 15 of the forward substitution (step_fwd above, factors taken from the packed chunk)
+// steps k0 .. k0 + 15 of the forward substitution; the column sits at col[0 .. ml) in LDS (zero beyond its length)
 template <int P>
-__device__ __forceinline__ void ldsp_step_fwd (PackChunk<P> &c, double *lds, int s, int len, int k0, double (&w)[P])
+__device__ __forceinline__ void ldsp_step_fwd (PackChunk<P> &c, double *col, int k0, double (&w)[P])
 {
    double b[16];
 #pragma unroll
-   for (int j = 0; j < 16; j++) b[j] = (k0 + j < len) ? lds[LDS_PAD (s + k0 + j)] : 0.0;
+   for (int j = 0; j < 16; j++) b[j] = col[k0 + j];
 #pragma unroll
    for (int j4 = 0; j4 < 4; j4++) {
 #pragma unroll
@@ -1000,23 +1000,22 @@ __device__ __forceinline__ void ldsp_step_fwd (PackChunk<P> &c, double *lds, int
          const int j = 4 * j4 + i;
          double y = b[j];
 #pragma unroll
-         for (int q = P; q >= 1; q--)
-            if (k0 + j - q >= 0) y -= (double) ldsp_elem (c.q[q - 1][j4], i) * w[q - 1];
+         for (int q = P; q >= 1; q--) y -= (double) ldsp_elem (c.q[q - 1][j4], i) * w[q - 1];     // steps before the column's first: w = 0
 #pragma unroll
          for (int q = P - 1; q >= 1; q--) w[q] = w[q - 1];
          w[0] = y;
-         if (k0 + j < len) lds[LDS_PAD (s + k0 + j)] = y;
+         col[k0 + j] = y;
       }
    }
 }
 
-// steps k0 + 15 .. k0 of the back substitution (step_bwd above)
+// steps k0 + 15 .. k0 of the back substitution
 template <int P>
-__device__ __forceinline__ void ldsp_step_bwd (PackChunk<P> &c, double *lds, int s, int len, int k0, double (&u)[P])
+__device__ __forceinline__ void ldsp_step_bwd (PackChunk<P> &c, double *col, int k0, double (&u)[P])
 {
    double y[16];
 #pragma unroll
-   for (int j = 0; j < 16; j++) y[j] = (k0 + j < len) ? lds[LDS_PAD (s + k0 + j)] : 0.0;
+   for (int j = 0; j < 16; j++) y[j] = col[k0 + j];
 #pragma unroll
    for (int j4 = 3; j4 >= 0; j4--) {
 #pragma unroll
@@ -1031,31 +1030,35 @@ __device__ __forceinline__ void ldsp_step_bwd (PackChunk<P> &c, double *lds, int
 #pragma unroll
          for (int q = P - 1; q >= 1; q--) u[q] = u[q - 1];
          u[0] = x;
-         if (k0 + j < len) lds[LDS_PAD (s + k0 + j)] = x;
+         col[k0 + j] = x;
       }
    }
 }
 
+// LDS image: column l of the group at [l * LDSP_STRIDE, ...), LDSP_STRIDE = NCH * 16 + 1 doubles.  Odd stride: the 32 lanes of
+// a substitution step hit 32 different bank pairs; fixed stride: every LDS address of the sweeps is "lane base + constant",
+// no address arithmetic and no predicate (SQ counters of the first version: 21 VALU instructions per step, most of them
+// the padded index of the linear image, and 41 % of a wave's life spent issuing).  Rows beyond a column's length are zero
+// (their factors are zero too), so the sweeps need no length test.
 template <int P, int NCH>
 __global__ __launch_bounds__ (NKP_WAVE, 2)
 void colblock_apply_ldspack_kernel (const int *__restrict__ grp_nb, const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
                                     const float *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
                                     const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp)
 {
-   extern __shared__ double lds[];            // the group's right-hand side, then its solution
-   constexpr int gw = 32, CH = 16;
+   extern __shared__ double lds[];
+   constexpr int gw = 32, CH = 16, STRIDE = NCH * CH + 1;
    constexpr LdspSchedule<NCH, P * CH, (P + 1) * CH> S;
    const int g = blockIdx.x + g_first;
    const int lane = threadIdx.x;
-   const int nb = grp_nb[g], ml = grp_maxlen[g];            // ml is a multiple of 16, at most NCH * 16
+   const int ml = grp_maxlen[g];                            // a multiple of 16, at most NCH * 16
    const int nch = ml / CH, mlq = ml >> 2;
-   const int R0 = grp_row0[g], nrows = grp_row0[ngrp + g];
-   // lanes >= 32 own no column: they help to stage the right-hand side, and their (unused) factor loads repeat lane - 32's
+   const int R0 = grp_row0[g];
    const int cl = lane & (gw - 1);
-   int s = 0, len = 0;
-   if (lane < gw) { s = col_slot[g * gw + lane]; len = col_slot[(ngrp + g) * gw + lane]; }
+   // first row (within the group) and length of lane's column; lanes 32-63 mirror 0-31 (the staging loops broadcast from them)
+   const int s = col_slot[g * gw + cl], len = col_slot[(ngrp + g) * gw + cl];
    const float4 *f4 = reinterpret_cast<const float4 *> (fac_t + grp_base[g]) + cl;
-   // The loads are unconditional so that the whole kernel is one straight line the static schedule can be written into: a
+   // The factor loads are unconditional so that the kernel is one straight line the static schedule can be written into: a
    // group with fewer than NCH chunks requests its last chunk again (an L2 hit) and skips the steps.
    // F[c] = forward chunk min (c, nch - 1);  Bq[j] = backward chunk max (nch - 1 - j, 0)
 #define LDSP_FWD_K0(t) (((t) < nch ? (t) : nch - 1) * CH)
@@ -1067,46 +1070,70 @@ void colblock_apply_ldspack_kernel (const int *__restrict__ grp_nb, const int *_
 #pragma unroll
    for (int t = 0; t < NCH; t++)
       if (t < S.b_upfront) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
-   for (int i0 = lane; i0 < nrows; i0 += 8 * NKP_WAVE) {
-      double t[8];
+   // staging, one column per step: 64 lanes read up to 64 consecutive rows of column c (coalesced) and write them to its slot,
+   // zeros behind its end; 8 columns' loads are in flight together
 #pragma unroll
-      for (int u = 0; u < 8; u++) t[u] = (i0 + u * NKP_WAVE < nrows) ? rhs[(int64_t) R0 + i0 + u * NKP_WAVE] : 0.0;
+   for (int c0 = 0; c0 < gw; c0 += 8) {
+      double t[8], t2[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-         if (i0 + u * NKP_WAVE < nrows) lds[LDS_PAD (i0 + u * NKP_WAVE)] = t[u];
+      for (int u = 0; u < 8; u++) {
+         const int sc = __builtin_amdgcn_readlane (s, c0 + u), lc = __builtin_amdgcn_readlane (len, c0 + u);
+         t[u] = (lane < lc) ? rhs[(int64_t) R0 + sc + lane] : 0.0;
+         if (NCH > 4) t2[u] = (lane + NKP_WAVE < lc) ? rhs[(int64_t) R0 + sc + lane + NKP_WAVE] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         lds[(c0 + u) * STRIDE + lane] = t[u];
+         if (NCH > 4 && lane < STRIDE - 1 - NKP_WAVE) lds[(c0 + u) * STRIDE + lane + NKP_WAVE] = t2[u];
+      }
    }
    __syncthreads ();
-   // every lane walks the schedule (idle lanes on zero-length columns: no LDS traffic), so there is no divergent region
-   if (lane >= nb) len = 0;
-   double w[P];
+   if (lane < gw) {
+      double *col = lds + lane * STRIDE;
+      double w[P];
 #pragma unroll
-   for (int q = 0; q < P; q++) w[q] = 0.0;
+      for (int q = 0; q < P; q++) w[q] = 0.0;
 #pragma unroll
-   for (int c = 0; c < NCH; c++) {
-      if (c < nch) ldsp_step_fwd<P> (F[c], lds, s, len, c * CH, w);
+      for (int c = 0; c < NCH; c++) {
+         if (c < nch) ldsp_step_fwd<P> (F[c], col, c * CH, w);
 #pragma unroll
-      for (int t = 0; t < NCH; t++)
-         if (t >= (c ? S.f_after[c - 1] : S.f_upfront) && t < S.f_after[c]) ldsp_load_fwd<P> (F[t], f4, mlq, LDSP_FWD_K0 (t), gw);
+         for (int t = 0; t < NCH; t++)
+            if (t >= (c ? S.f_after[c - 1] : S.f_upfront) && t < S.f_after[c]) ldsp_load_fwd<P> (F[t], f4, mlq, LDSP_FWD_K0 (t), gw);
 #pragma unroll
-      for (int t = 0; t < NCH; t++)
-         if (t >= (c ? S.b_after_f[c - 1] : S.b_upfront) && t < S.b_after_f[c]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
-   }
+         for (int t = 0; t < NCH; t++)
+            if (t >= (c ? S.b_after_f[c - 1] : S.b_upfront) && t < S.b_after_f[c]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+      }
 #pragma unroll
-   for (int q = 0; q < P; q++) w[q] = 0.0;
+      for (int q = 0; q < P; q++) w[q] = 0.0;
 #pragma unroll
-   for (int j = 0; j < NCH; j++) {
-      if (j < nch) ldsp_step_bwd<P> (Bq[j], lds, s, len, (nch - 1 - j) * CH, w);
+      for (int j = 0; j < NCH; j++) {
+         if (j < nch) ldsp_step_bwd<P> (Bq[j], col, (nch - 1 - j) * CH, w);
 #pragma unroll
-      for (int t = 0; t < NCH; t++)
-         if (t >= (j ? S.b_after_b[j - 1] : S.b_after_f[NCH - 1]) && t < S.b_after_b[j]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+         for (int t = 0; t < NCH; t++)
+            if (t >= (j ? S.b_after_b[j - 1] : S.b_after_f[NCH - 1]) && t < S.b_after_b[j]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+      }
    }
 #undef LDSP_FWD_K0
 #undef LDSP_BWD_K0
    __syncthreads ();
-   if (accumulate)
-      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] += lds[LDS_PAD (i)];
-   else
-      for (int i = lane; i < nrows; i += NKP_WAVE) z[(int64_t) R0 + i] = lds[LDS_PAD (i)];
+   // back out, one column per step; the accumulate target of 8 columns is requested together
+#pragma unroll
+   for (int c0 = 0; c0 < gw; c0 += 8) {
+      double t[8], t2[8];
+      int sc[8], lc[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         sc[u] = __builtin_amdgcn_readlane (s, c0 + u);
+         lc[u] = __builtin_amdgcn_readlane (len, c0 + u);
+         t[u] = (accumulate && lane < lc[u]) ? z[(int64_t) R0 + sc[u] + lane] : 0.0;
+         if (NCH > 4) t2[u] = (accumulate && lane + NKP_WAVE < lc[u]) ? z[(int64_t) R0 + sc[u] + lane + NKP_WAVE] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         if (lane < lc[u]) z[(int64_t) R0 + sc[u] + lane] = t[u] + lds[(c0 + u) * STRIDE + lane];
+         if (NCH > 4 && lane + NKP_WAVE < lc[u]) z[(int64_t) R0 + sc[u] + lane + NKP_WAVE] = t2[u] + lds[(c0 + u) * STRIDE + lane + NKP_WAVE];
+      }
+   }
 }
 
 template <class T>
@@ -1212,6 +1239,7 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       if ((rc2 = up (&B.gs_rb_ptr, rb_ptr, device_bytes)) || (rc2 = up (&B.gs_rb, rb_bd, device_bytes))) return rc2;
    }
    B.ngrp = (int) b0.size ();
+   if (B.ldsres == 2) lds_need = std::max (lds_need, 32 * ((B.max_len <= 64 ? 4 : 5) * NKP_LDSRES_CH + 1));     // one fixed-stride slot per column
    lds_need = (lds_need + 1) & ~1;                 // keep the factor area 16-byte aligned
    B.rhs_slots = lds_need;
    if (!B.stream && !B.ldsres) lds_need += f32 ? (fac_need + 1) / 2 : fac_need;      // doubles

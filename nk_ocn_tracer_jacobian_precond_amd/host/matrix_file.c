@@ -191,6 +191,73 @@ int get_sparse_matrix (char *fname)
    return 0;
 }
 
+/* dims, coupled_tracer_cnt and rowptr: what every rank of the row-distributed flavour needs of the matrix before it knows
+ * its rows (reference: rank 0 reads everything and sends rowptr slices, src/solve_ABdist.c:141-175) */
+int get_sparse_matrix_header (char *fname)
+{
+   char *subname = "get_sparse_matrix_header";
+   char *names[2] = { "nnz", "flat_len_p1" };
+   size_t lens[2];
+
+   trace ("entering", subname);
+   if (read_dimlens (subname, fname, 2, names, lens))
+      return 1;
+   if (lens[0] > 2147483647u || lens[1] == 0 || lens[1] > 2147483647u) {
+      fprintf (stderr, "(%d) %s: nnz=%zu flat_len_p1=%zu outside the int32 schema\n", iam, subname, lens[0], lens[1]);
+      return 1;
+   }
+   nnz = (int) lens[0];
+   flat_len = (int) lens[1] - 1;
+   if (get_var_1d_int (fname, "coupled_tracer_cnt", &coupled_tracer_cnt))
+      return 1;
+   rowptr = (int_t *) malloc ((size_t) (flat_len + 1) * sizeof (int_t));
+   if (!rowptr) {
+      fprintf (stderr, "(%d) malloc failed in %s for rowptr\n", iam, subname);
+      return 1;
+   }
+   if (get_var_1d_int (fname, "rowptr", rowptr))
+      return 1;
+   if (rowptr[0] != 0 || rowptr[flat_len] != nnz) {
+      fprintf (stderr, "(%d) %s: rowptr[0]=%d rowptr[flat_len]=%d inconsistent with nnz=%d\n", iam, subname, rowptr[0], rowptr[flat_len], nnz);
+      return 1;
+   }
+   for (int r = 0; r < flat_len; r++)
+      if (rowptr[r + 1] < rowptr[r]) {
+         fprintf (stderr, "(%d) %s: rowptr decreases at row %d\n", iam, subname, r);
+         return 1;
+      }
+   trace ("exiting", subname);
+   return 0;
+}
+
+/* entries of rows [row0, row1) (the reference's colind / nzval slices, src/solve_ABdist.c:188-225); needs the header */
+int get_sparse_matrix_rows (char *fname, int row0, int row1, int_t *colind_out, double *nzval_out)
+{
+   char *subname = "get_sparse_matrix_rows";
+   trace ("entering", subname);
+   if (!rowptr || row0 < 0 || row1 < row0 || row1 > flat_len) {
+      fprintf (stderr, "(%d) %s: rows [%d, %d) outside the matrix (or get_sparse_matrix_header not called)\n", iam, subname, row0, row1);
+      return 1;
+   }
+   const size_t e0 = (size_t) rowptr[row0], cnt = (size_t) (rowptr[row1] - rowptr[row0]);
+   if (cnt) {
+      if (get_vara_1d_double (fname, "nzval_row_wise", e0, cnt, nzval_out))
+         return 1;
+      if (get_vara_1d_int (fname, "colind", e0, cnt, colind_out))
+         return 1;
+   }
+   for (int r = row0; r < row1; r++)
+      for (int e = rowptr[r]; e < rowptr[r + 1]; e++) {
+         const int_t c = colind_out[(size_t) e - e0];
+         if (c < 0 || c >= flat_len || (e > rowptr[r] && c <= colind_out[(size_t) e - e0 - 1])) {
+            fprintf (stderr, "(%d) %s: row %d has an out-of-range or unsorted column index %d\n", iam, subname, r, c);
+            return 1;
+         }
+      }
+   trace ("exiting", subname);
+   return 0;
+}
+
 void free_sparse_matrix (void)
 {
    trace ("entering", "free_sparse_matrix");

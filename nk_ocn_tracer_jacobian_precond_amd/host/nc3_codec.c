@@ -244,6 +244,7 @@ const char *nc3_strerror (int status)
    case NC3_ENOTINDEFINE: return "NetCDF: Operation not allowed in data mode";
    case NC3_EINDEFINE: return "NetCDF: Operation not allowed in define mode";
    case NC3_EINVAL: return "NetCDF: Invalid Argument";
+   case NC3_EEDGE: return "NetCDF: Start+count exceeds dimension bound";
    default: return "NetCDF: Unknown error";
    }
 }
@@ -347,7 +348,9 @@ static inline int encode_double (unsigned char *p, int type, double x)
 
 typedef enum { AS_DOUBLE, AS_INT } mem_t;
 
-static int transfer (nc3_file *f, int varid, void *mem, mem_t mt, int writing)
+/* first / count: a range of the variable's elements in storage order (a hyperslab of a 1-D variable); count = UINT64_MAX
+ * moves the whole variable.  Ranges are for fixed-size variables: a record variable's elements are not contiguous. */
+static int transfer (nc3_file *f, int varid, void *mem, mem_t mt, int writing, uint64_t first, uint64_t count)
 {
    if (varid < 0 || varid >= f->nvars) return NC3_ENOTVAR;
    if (f->defining) return NC3_EINDEFINE;
@@ -355,6 +358,8 @@ static int transfer (nc3_file *f, int varid, void *mem, mem_t mt, int writing)
    var_t *v = &f->vars[varid];
    int esz = type_size[v->type];
    uint64_t nrec = v->is_record ? f->numrecs : 1;
+   const int ranged = count != UINT64_MAX;
+   if (ranged && (v->is_record || first > v->per_rec || count > v->per_rec - first)) return NC3_EEDGE;
    size_t chunk = CHUNK_ELEMS;
    unsigned char *buf = (unsigned char *) malloc (chunk * (size_t) esz);
    if (!buf) return NC3_ENOMEM;
@@ -362,9 +367,9 @@ static int transfer (nc3_file *f, int varid, void *mem, mem_t mt, int writing)
    uint64_t done = 0;
 
    for (uint64_t r = 0; r < nrec; r++) {
-      int64_t off = v->begin + (int64_t) (r * f->recsize);
+      int64_t off = v->begin + (int64_t) (r * f->recsize) + (ranged ? (int64_t) (first * (uint64_t) esz) : 0);
       if (fseeko (f->fp, (off_t) off, SEEK_SET)) { free (buf); return NC3_EIO; }
-      uint64_t left = v->per_rec;
+      uint64_t left = ranged ? count : v->per_rec;
       while (left) {
          size_t m = left < chunk ? (size_t) left : chunk;
          if (!writing) {
@@ -437,10 +442,12 @@ static int transfer (nc3_file *f, int varid, void *mem, mem_t mt, int writing)
    return range_err ? NC3_ERANGE : NC3_NOERR;
 }
 
-int nc3_get_var_double (nc3_file *f, int varid, double *out) { return transfer (f, varid, out, AS_DOUBLE, 0); }
-int nc3_get_var_int (nc3_file *f, int varid, int *out) { return transfer (f, varid, out, AS_INT, 0); }
-int nc3_put_var_double (nc3_file *f, int varid, const double *in) { return transfer (f, varid, (void *) in, AS_DOUBLE, 1); }
-int nc3_put_var_int (nc3_file *f, int varid, const int *in) { return transfer (f, varid, (void *) in, AS_INT, 1); }
+int nc3_get_var_double (nc3_file *f, int varid, double *out) { return transfer (f, varid, out, AS_DOUBLE, 0, 0, UINT64_MAX); }
+int nc3_get_var_int (nc3_file *f, int varid, int *out) { return transfer (f, varid, out, AS_INT, 0, 0, UINT64_MAX); }
+int nc3_put_var_double (nc3_file *f, int varid, const double *in) { return transfer (f, varid, (void *) in, AS_DOUBLE, 1, 0, UINT64_MAX); }
+int nc3_put_var_int (nc3_file *f, int varid, const int *in) { return transfer (f, varid, (void *) in, AS_INT, 1, 0, UINT64_MAX); }
+int nc3_get_vara_double (nc3_file *f, int varid, size_t first, size_t count, double *out) { return transfer (f, varid, out, AS_DOUBLE, 0, first, count); }
+int nc3_get_vara_int (nc3_file *f, int varid, size_t first, size_t count, int *out) { return transfer (f, varid, out, AS_INT, 0, first, count); }
 
 int nc3_get_att_double (nc3_file *f, int varid, const char *attname, double *val)
 {

@@ -32,7 +32,8 @@ enum {
    NC3_ENAMEINUSE = -42,  /* dimension / variable name already defined */
    NC3_ENOTINDEFINE = -38,/* definition call outside define mode */
    NC3_EINDEFINE = -39,   /* data call while in define mode */
-   NC3_EINVAL = -36
+   NC3_EINVAL = -36,
+   NC3_EEDGE = -57        /* start + count exceeds the variable (libnetcdf's NC_EEDGE), or a range of a record variable */
 };
 
 enum { NC3_BYTE = 1, NC3_CHAR, NC3_SHORT, NC3_INT, NC3_FLOAT, NC3_DOUBLE,
@@ -55,6 +56,9 @@ int nc3_inq_var_dimlens (nc3_file *f, int varid, size_t *dimlens /* ndims entrie
 int nc3_get_var_double (nc3_file *f, int varid, double *out);
 int nc3_get_var_int (nc3_file *f, int varid, int *out);
 int nc3_put_var_double (nc3_file *f, int varid, const double *in);
+/* elements [first, first + count) of a fixed-size variable in storage order (nc_get_vara on a 1-D variable) */
+int nc3_get_vara_double (nc3_file *f, int varid, size_t first, size_t count, double *out);
+int nc3_get_vara_int (nc3_file *f, int varid, size_t first, size_t count, int *out);
 int nc3_put_var_int (nc3_file *f, int varid, const int *in);
 /* numeric attribute of a variable (varid -1 = global), first element, as double */
 int nc3_get_att_double (nc3_file *f, int varid, const char *attname, double *val);

@@ -50,6 +50,9 @@ void free_3d_double (double ***ptr);
 int handle_nc_error (char *subname, char *cdf_subname, char *msg, int status);
 int var_exists_in_file (char *fname, char *varname, int *retval);
 int get_att_double (char *fname, char *varname, char *attname, double *val);
+/* additions of this build: a range of a 1-D variable */
+int get_vara_1d_int (char *fname, char *varname, size_t first, size_t count, int *field);
+int get_vara_1d_double (char *fname, char *varname, size_t first, size_t count, double *field);
 int get_var_1d_int (char *fname, char *varname, int *field);
 int get_var_2d_int (char *fname, char *varname, int **field);
 int get_var_3d_int (char *fname, char *varname, int ***field);
@@ -99,6 +102,12 @@ extern int_t *rowptr;
 int get_ind_maps (char *fname);
 void free_ind_maps (void);
 int get_sparse_matrix (char *fname);
+/* additions of this build (row-distributed flavour: every rank reads its own rows, not the whole matrix):
+ * get_sparse_matrix_header = dims, coupled_tracer_cnt and the row pointers only (colind / nzval_row_wise stay NULL);
+ * get_sparse_matrix_rows = the entries of rows [row0, row1) into caller arrays of rowptr[row1] - rowptr[row0] elements,
+ * with the same structural checks get_sparse_matrix applies. */
+int get_sparse_matrix_header (char *fname);
+int get_sparse_matrix_rows (char *fname, int row0, int row1, int_t *colind_out, double *nzval_out);
 void free_sparse_matrix (void);
 
 /* ---- matrix generator (reference src/matrix.h:6-9,26-56,70-81; src/matrix.c:163-369, 466-3939) */

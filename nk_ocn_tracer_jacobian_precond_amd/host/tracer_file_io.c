@@ -60,6 +60,31 @@ int put_var_1d_double (char *fname, char *varname, double *field) { return whole
 int put_var_2d_double (char *fname, char *varname, double **field) { return whole_var ("put_var_2d_double", fname, varname, XFER_PUT_DOUBLE, field[0]); }
 int put_var_3d_double (char *fname, char *varname, double ***field) { return whole_var ("put_var_3d_double", fname, varname, XFER_PUT_DOUBLE, field[0][0]); }
 
+/* elements [first, first + count) of a 1-D variable: what a rank of solve_ABdist reads of the matrix arrays instead of the
+ * whole variable (the reference has rank 0 read everything and send slices, src/solve_ABdist.c:141-225) */
+static int part_var (char *subname, char *fname, char *varname, int as_double, size_t first, size_t count, void *out)
+{
+   nc3_file *f;
+   int status, varid;
+   if ((status = nc3_open (fname, 0, &f)))
+      return handle_nc_error (subname, "nc_open", fname, status);
+   if ((status = nc3_inq_varid (f, varname, &varid))) {
+      nc3_close (f);
+      return handle_nc_error (subname, "nc_inq_varid", varname, status);
+   }
+   status = as_double ? nc3_get_vara_double (f, varid, first, count, (double *) out) : nc3_get_vara_int (f, varid, first, count, (int *) out);
+   if (status) {
+      nc3_close (f);
+      return handle_nc_error (subname, as_double ? "nc_get_vara_double" : "nc_get_vara_int", varname, status);
+   }
+   if ((status = nc3_close (f)))
+      return handle_nc_error (subname, "nc_close", fname, status);
+   return 0;
+}
+
+int get_vara_1d_int (char *fname, char *varname, size_t first, size_t count, int *field) { return part_var ("get_vara_1d_int", fname, varname, 0, first, count, field); }
+int get_vara_1d_double (char *fname, char *varname, size_t first, size_t count, double *field) { return part_var ("get_vara_1d_double", fname, varname, 1, first, count, field); }
+
 int var_exists_in_file (char *fname, char *varname, int *retval)
 {
    char *subname = "var_exists_in_file";

@@ -121,3 +121,33 @@ def test_errors(tmp_path, host, capfd):
     fv = C.c_double()
     assert host.get_att_double(dst.encode(), b"IAGE", b"_FillValue", C.byref(fv)) == 0
     assert fv.value == synth.FILL_DOUBLE
+
+
+def test_row_slices_of_the_matrix_file(golden, host, capfd):
+    """What a rank of solve_ABdist reads when there are several (get_sparse_matrix_header + get_sparse_matrix_rows: the
+    reference's rowptr / colind / nzval slices, src/solve_ABdist.c:141-225, read straight from the file as hyperslabs):
+    any row range gives exactly the entries of those rows; ranges outside the variable are refused."""
+    path = golden.matrix_path.encode()
+    assert host.get_sparse_matrix_header(path) == 0
+    n = C.c_int.in_dll(host, "flat_len").value
+    assert n == golden.n and C.c_int.in_dll(host, "nnz").value == golden.colind.size
+    assert not C.POINTER(C.c_int).in_dll(host, "colind")                 # header only: no entry arrays
+    rp = np.ctypeslib.as_array(C.POINTER(C.c_int).in_dll(host, "rowptr"), (n + 1,)).copy()
+    assert np.array_equal(rp, golden.rowptr)
+    host.get_sparse_matrix_rows.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    for r0, r1 in ((0, n), (0, 1), (n // 3, 2 * n // 3), (n - 1, n), (5, 5)):
+        cnt = int(rp[r1] - rp[r0])
+        ci, v = np.full(cnt + 1, -7, np.int32), np.full(cnt + 1, np.nan)
+        assert host.get_sparse_matrix_rows(path, r0, r1, ci.ctypes.data_as(C.POINTER(C.c_int)), v.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        assert np.array_equal(ci[:cnt], golden.colind[rp[r0]:rp[r1]]) and np.array_equal(v[:cnt], golden.val[rp[r0]:rp[r1]])
+        assert ci[cnt] == -7                                             # nothing written past the range
+    assert host.get_sparse_matrix_rows(path, 3, n + 1, None, None) == 1
+    assert "outside the matrix" in capfd.readouterr().err
+    host.free_sparse_matrix()
+    # the codec's range check (libnetcdf's NC_EEDGE)
+    host.get_vara_1d_int.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+    buf = np.zeros(4, np.int32)
+    assert host.get_vara_1d_int(path, b"rowptr", n, 2, buf.ctypes.data_as(C.POINTER(C.c_int))) != 0
+    assert "exceeds dimension bound" in capfd.readouterr().err
+    assert host.get_vara_1d_int(path, b"rowptr", n - 1, 2, buf.ctypes.data_as(C.POINTER(C.c_int))) == 0
+    assert list(buf[:2]) == list(golden.rowptr[n - 1:n + 1])
