@@ -943,79 +943,88 @@ static void term_hmix_isop (const row_ctx *R, double *v, void *arg)
    }
 }
 
+/* The 36 impulse-response fields of the isopycnal mixing operator (reference src/matrix.c:2233-2259): field q of the
+ * (4, 3, 3) colouring is stored under one of the spellings below, tried in this order. */
+static const char *const irf_spellings[] = { "HDIF_EXPLICIT_3D_IRF_%d_%d_%d", "HDIF_EXPLICIT_3D_IRF_NK_%d_%d_%d" };
+
+/* name of the colouring's field (ip, jp, kp) as the circulation file spells it; 0 found, 1 absent under every spelling, -1 I/O error */
+static int irf_field_name (const char *subname, int ip, int jp, int kp, char *name, size_t cap)
+{
+   for (size_t v = 0; v < sizeof irf_spellings / sizeof irf_spellings[0]; v++) {
+      int present = 0;
+      snprintf (name, cap, irf_spellings[v], ip + 1, jp + 1, kp + 1);
+      if (var_exists_in_file (circ_fname, name, &present)) {
+         fprintf (stderr, "(%d) var_exists_in_file failed in %s for field_name %s in file %s\n", iam, subname, name, circ_fname);
+         return -1;
+      }
+      if (present)
+         return 0;
+      if (dbg_lvl)
+         printf ("(%d) %s: %s not found in %s\n", iam, subname, name, circ_fname);
+   }
+   return 1;
+}
+
 static int add_hmix_isop_file (void)
 {
    char *subname = "add_hmix_isop_file";
    irf_arg A;
-   char IRF_name[64];
-   int var_exists;
+   char field[64];
+   int rc = 0;
 
    trace ("entering", subname);
    if ((A.IRF = malloc_3d_double (km, jmt, imt)) == NULL) {
       fprintf (stderr, "(%d) malloc failed in %s for IRF\n", iam, subname);
       return 1;
    }
-   for (A.iprime = 0; A.iprime < 4; A.iprime++)
-      for (A.jprime = 0; A.jprime < 3; A.jprime++)
-         for (A.kprime = 0; A.kprime < 3; A.kprime++) {
-            sprintf (IRF_name, "HDIF_EXPLICIT_3D_IRF_%d_%d_%d", A.iprime + 1, A.jprime + 1, A.kprime + 1);
-            if (var_exists_in_file (circ_fname, IRF_name, &var_exists)) {
-               fprintf (stderr, "(%d) var_exists_in_file failed in %s for field_name %s in file %s\n", iam, subname, IRF_name, circ_fname);
-               return 1;
-            }
-            if (!var_exists) {
-               if (dbg_lvl)
-                  printf ("(%d) %s: %s not found in %s\n", iam, subname, IRF_name, circ_fname);
-               sprintf (IRF_name, "HDIF_EXPLICIT_3D_IRF_NK_%d_%d_%d", A.iprime + 1, A.jprime + 1, A.kprime + 1);
-               if (var_exists_in_file (circ_fname, IRF_name, &var_exists)) {
-                  fprintf (stderr, "(%d) var_exists_in_file failed in %s for field_name %s in file %s\n", iam, subname, IRF_name, circ_fname);
-                  return 1;
-               }
-               if (!var_exists) {
-                  if (dbg_lvl)
-                     printf ("(%d) %s: %s not found in %s\n", iam, subname, IRF_name, circ_fname);
-                  return 1;
-               }
-            }
-            if (dbg_lvl)
-               printf ("(%d) %s: reading %s from %s\n", iam, subname, IRF_name, circ_fname);
-            {
-               double t0 = now_s ();
-               if (get_var_3d_double (circ_fname, IRF_name, A.IRF))
-                  return 1;
-               t_read += now_s () - t0;
-            }
-            for_rows (term_hmix_isop, &A);
-         }
+   /* q enumerates the colouring with kprime fastest, like the reference's loop nest */
+   for (int q = 0; q < 4 * 3 * 3 && !rc; q++) {
+      A.iprime = q / 9;
+      A.jprime = (q / 3) % 3;
+      A.kprime = q % 3;
+      if (irf_field_name (subname, A.iprime, A.jprime, A.kprime, field, sizeof field)) {
+         rc = 1;
+         break;
+      }
+      if (dbg_lvl)
+         printf ("(%d) %s: reading %s from %s\n", iam, subname, field, circ_fname);
+      const double t0 = now_s ();
+      rc = get_var_3d_double (circ_fname, field, A.IRF) != 0;
+      t_read += now_s () - t0;
+      if (!rc)
+         for_rows (term_hmix_isop, &A);
+   }
+   if (rc)
+      return 1;
    free_3d_double (A.IRF);
    trace ("exiting", subname);
    return 0;
 }
+
+/* lateral mixing by option: the routine that adds it, and the advection scheme it cannot be combined with (-1: none) */
+static const struct {
+   int (*add) (void);
+   int refuses_adv;
+   const char *why;
+} hmix_table[] = {
+   [hmix_none] = { NULL, -1, NULL },
+   [hmix_const] = { add_hmix_const, -1, NULL },
+   [hmix_hor_file] = { add_hmix_hor_file, adv_upwind3, "cannot use hmix_hor_file with adv_upwind3" },
+   [hmix_isop_file] = { add_hmix_isop_file, -1, NULL },
+};
 
 static int add_hmix (void)
 {
    char *subname = "add_hmix";
 
    trace ("entering", subname);
-   switch (hmix_opt) {
-   case hmix_none:
-      break;
-   case hmix_const:
-      if (add_hmix_const ())
-         return 1;
-      break;
-   case hmix_hor_file:
-      if (adv_opt == adv_upwind3) {
-         fprintf (stderr, "(%d) cannot use hmix_hor_file with adv_upwind3\n", iam);
+   if ((size_t) hmix_opt < sizeof hmix_table / sizeof hmix_table[0] && hmix_table[hmix_opt].add) {
+      if (hmix_table[hmix_opt].refuses_adv == (int) adv_opt) {
+         fprintf (stderr, "(%d) %s\n", iam, hmix_table[hmix_opt].why);
          return 1;
       }
-      if (add_hmix_hor_file ())
+      if (hmix_table[hmix_opt].add ())
          return 1;
-      break;
-   case hmix_isop_file:
-      if (add_hmix_isop_file ())
-         return 1;
-      break;
    }
    if (dbg_lvl)
       printf ("(%d) hmix terms added\n\n", iam);
