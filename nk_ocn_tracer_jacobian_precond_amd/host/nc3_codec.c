@@ -3,6 +3,7 @@
  * payloads padded to 4 bytes; record variables interleaved per record). */
 #define _FILE_OFFSET_BITS 64
 #include "nc3_codec.h"
+#include "nc4_hdf5.h"
 
 #include <limits.h>
 #include <math.h>
@@ -31,6 +32,7 @@ typedef struct {
 } var_t;
 
 struct nc3_file {
+   nc4_file *h4;                /* a netCDF-4 / HDF5 container: every call goes to nc4_hdf5.c, nothing below is used */
    FILE *fp;
    char *path;
    int writable;
@@ -119,6 +121,7 @@ int nc3_close (nc3_file *f)
 {
    int status = NC3_NOERR;
    if (!f) return NC3_NOERR;
+   if (f->h4) { status = nc4_close (f->h4); free (f); return status; }
    if (f->defining) status = nc3_enddef (f);
    if (f->fp && fclose (f->fp) && !status) status = NC3_EIO;
    for (int i = 0; i < f->ndims; i++) free (f->dims[i].name);
@@ -143,7 +146,19 @@ int nc3_open (const char *path, int writable, nc3_file **out)
    if (!fp) return NC3_EIO;
    unsigned char magic[4];
    if (fread (magic, 1, 4, fp) != 4) { fclose (fp); return NC3_ENOTNC; }
-   if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F') { fclose (fp); return NC3_EHDF5; }
+   if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F') {
+      /* netCDF-4: read and written through libhdf5 when one can be loaded, refused (NC3_EHDF5) otherwise */
+      fclose (fp);
+      nc4_file *h4 = NULL;
+      const int st = nc4_open (path, writable, &h4);
+      if (st) return st;
+      nc3_file *f4 = (nc3_file *) calloc (1, sizeof (nc3_file));
+      if (!f4) { nc4_close (h4); return NC3_ENOMEM; }
+      f4->h4 = h4;
+      f4->writable = writable;
+      *out = f4;
+      return NC3_NOERR;
+   }
    if (magic[0] != 'C' || magic[1] != 'D' || magic[2] != 'F' || (magic[3] != 1 && magic[3] != 2 && magic[3] != 5)) {
       fclose (fp);
       return NC3_ENOTNC;
@@ -236,7 +251,8 @@ const char *nc3_strerror (int status)
    case NC3_ENOTNC: return "NetCDF: Unknown file format";
    case NC3_ERANGE: return "NetCDF: Numeric conversion not representable";
    case NC3_ENOMEM: return "NetCDF: Memory allocation (malloc) failure";
-   case NC3_EHDF5: return "NetCDF: netCDF-4/HDF5 files are not supported by this build (classic CDF-1/2/5 only)";
+   case NC3_EHDF5OPEN: return "NetCDF: the file carries the HDF5 signature but libhdf5 could not open it";
+   case NC3_EHDF5: return "NetCDF: a netCDF-4/HDF5 file, and no libhdf5 (>= 1.10) could be loaded to read it (NKP_HDF5_LIB names one; classic CDF-1/2/5 files need none; nccopy -k cdf5 converts)";
    case NC3_ENOTATT: return "NetCDF: Attribute not found";
    case NC3_EIO: return "NetCDF: I/O failure (open, seek, read or write)";
    case NC3_EPERM: return "NetCDF: Write to read only";
@@ -253,6 +269,7 @@ const char *nc3_strerror (int status)
 
 int nc3_inq_dimlen (nc3_file *f, const char *dimname, size_t *len)
 {
+   if (f->h4) return nc4_inq_dimlen (f->h4, dimname, len);
    for (int i = 0; i < f->ndims; i++)
       if (strcmp (f->dims[i].name, dimname) == 0) {
          *len = (size_t) (f->dims[i].len ? f->dims[i].len : f->numrecs);
@@ -263,6 +280,7 @@ int nc3_inq_dimlen (nc3_file *f, const char *dimname, size_t *len)
 
 int nc3_inq_varid (nc3_file *f, const char *varname, int *varid)
 {
+   if (f->h4) return nc4_inq_varid (f->h4, varname, varid);
    for (int i = 0; i < f->nvars; i++)
       if (strcmp (f->vars[i].name, varname) == 0) { *varid = i; return NC3_NOERR; }
    return NC3_ENOTVAR;
@@ -270,6 +288,7 @@ int nc3_inq_varid (nc3_file *f, const char *varname, int *varid)
 
 int nc3_inq_var (nc3_file *f, int varid, int *nc_type, int *ndims, size_t *nelems)
 {
+   if (f->h4) return nc4_inq_var (f->h4, varid, nc_type, ndims, nelems, NULL);
    if (varid < 0 || varid >= f->nvars) return NC3_ENOTVAR;
    var_t *v = &f->vars[varid];
    if (nc_type) *nc_type = v->type;
@@ -280,6 +299,7 @@ int nc3_inq_var (nc3_file *f, int varid, int *nc_type, int *ndims, size_t *nelem
 
 int nc3_inq_var_dimlens (nc3_file *f, int varid, size_t *dimlens)
 {
+   if (f->h4) return nc4_inq_var (f->h4, varid, NULL, NULL, NULL, dimlens);
    if (varid < 0 || varid >= f->nvars) return NC3_ENOTVAR;
    var_t *v = &f->vars[varid];
    for (int d = 0; d < v->ndims; d++) {
@@ -352,6 +372,7 @@ typedef enum { AS_DOUBLE, AS_INT } mem_t;
  * moves the whole variable.  Ranges are for fixed-size variables: a record variable's elements are not contiguous. */
 static int transfer (nc3_file *f, int varid, void *mem, mem_t mt, int writing, uint64_t first, uint64_t count)
 {
+   if (f->h4) return nc4_transfer (f->h4, varid, mt == AS_DOUBLE, writing, first, count, mem);
    if (varid < 0 || varid >= f->nvars) return NC3_ENOTVAR;
    if (f->defining) return NC3_EINDEFINE;
    if (writing && !f->writable) return NC3_EPERM;
@@ -451,6 +472,7 @@ int nc3_get_vara_int (nc3_file *f, int varid, size_t first, size_t count, int *o
 
 int nc3_get_att_double (nc3_file *f, int varid, const char *attname, double *val)
 {
+   if (f->h4) return nc4_get_att_double (f->h4, varid, attname, val);
    int n;
    att_t *a;
    if (varid == -1) { n = f->ngatts; a = f->gatts; }
@@ -488,6 +510,7 @@ int nc3_create (const char *path, int version, nc3_file **out)
 
 int nc3_redef (nc3_file *f)
 {
+   if (f->h4) return NC3_EHDF5;                 /* netCDF-4 files are read and updated in place, not extended */
    if (!f->writable) return NC3_EPERM;
    if (f->defining) return NC3_EINDEFINE;
    free (f->old_begin);

@@ -25,7 +25,8 @@ enum {
    NC3_ENOTNC = -51,      /* not a classic netCDF file */
    NC3_ERANGE = -60,      /* value not representable in the target type */
    NC3_ENOMEM = -61,
-   NC3_EHDF5 = -101,      /* netCDF-4/HDF5 container: unsupported here */
+   NC3_EHDF5 = -101,      /* netCDF-4/HDF5 container and no libhdf5 could be loaded to read it */
+   NC3_EHDF5OPEN = -102,  /* HDF5 signature, but libhdf5 cannot open the file (damaged, or not a netCDF-4 / HDF5 file at all) */
    NC3_ENOTATT = -43,
    NC3_EIO = -68,         /* open/seek/short read/short write */
    NC3_EPERM = -37,       /* write to a file opened read-only */

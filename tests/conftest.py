@@ -29,6 +29,7 @@ def _native_built():
             os.path.join(ROOT, "nk_ocn_tracer_jacobian_precond_amd", "csrc", "libnkp_hip.so"),
             os.path.join(ROOT, "nk_ocn_tracer_jacobian_precond_amd", "bin", "solve_ABglobal"),
             os.path.join(ROOT, "nk_ocn_tracer_jacobian_precond_amd", "bin", "gen_A"),
+            os.path.join(ROOT, "nk_ocn_tracer_jacobian_precond_amd", "bin", "nc_convert"),
             os.path.join(ROOT, "oracle", "libnkp_oracle.so")]
     if not all(os.path.exists(p) for p in need):
         build.build_all()

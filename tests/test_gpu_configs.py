@@ -19,18 +19,20 @@ def _solve(p, cnt=1, **kw):
         info["levels"] = s.get_int("levels")
     res = b - ora.spmv(p.rowptr, p.colind, p.nzval, x)
     info["true_relres"] = float(np.linalg.norm(res) / np.linalg.norm(b))
+    print(f"MEASURED n={p.flat_len} cnt={cnt} kw={kw} iters={info['iters']} status={info['status']} relres={info['true_relres']:.2e}")
     return info
 
 
-@pytest.mark.parametrize("refine", [1.0, 4.0, 12.0])
-def test_cell_courant_number_of_finer_grids(refine):
+# iteration bounds of this file: 1.3 x what round 3 measured (gpurun_out/r3i/configs.log), so that a regression shows
+@pytest.mark.parametrize("refine,bound", [(1.0, 72), (4.0, 52), (12.0, 54)])          # measured 55 / 40 / 41
+def test_cell_courant_number_of_finer_grids(refine, bound):
     """The 3 degree x 60 grid with the cell-level coefficients of a grid `refine` times finer (velocities x refine,
     lateral diffusivity x refine^2: cell Courant and diffusion numbers of 3, 0.75 and 0.25 degree).  Round 1 stalled
     here (the aggregates mixed unconnected water); the iteration count must now stay flat."""
     p = synth.generate(imt=100, jmt=116, km=60, adv="upwind3", hmix="isop", seed=0, u_scale=3.0 * refine, ah=4.0e6 * refine ** 2)
     info = _solve(p)
     assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
-    assert info["iters"] <= 90, info
+    assert info["iters"] <= bound, info
 
 
 def test_cell_courant_number_round1_recipe():
@@ -40,6 +42,7 @@ def test_cell_courant_number_round1_recipe():
     p = synth.generate(imt=100, jmt=116, km=60, adv="upwind3", hmix="isop", seed=0, u_scale=36.0, ah=4.0e6 * 144, isop_k33=False)
     info = _solve(p, max_iters=6000)
     assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
+    assert info["iters"] <= 1800, info                          # measured 1392
 
 
 def test_config_4tracer_1deg():
@@ -48,7 +51,7 @@ def test_config_4tracer_1deg():
     assert p.flat_len == 4 * p.tracer_state_len and p.flat_len > 16_000_000
     info = _solve(p, cnt=4, restart=100)
     assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
-    assert info["iters"] <= 250, info
+    assert info["iters"] <= 78, info                            # measured 60
 
 
 def test_config_quarter_degree():
@@ -58,7 +61,7 @@ def test_config_quarter_degree():
     assert p.flat_len > 50_000_000
     info = _solve(p, restart=60)
     assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
-    assert info["iters"] <= 400, info
+    assert info["iters"] <= 136, info                           # measured 105
 
 
 def test_coarsest_level_without_dense_inverse(monkeypatch):
@@ -72,8 +75,8 @@ def test_coarsest_level_without_dense_inverse(monkeypatch):
     assert info["iters"] <= 2 * ref["iters"] + 10, (info, ref)
 
 
-@pytest.mark.parametrize("adv,hmix,max_iters", [("donor", "isop", 120), ("centred", "isop", 600), ("upwind3", "const", 400), ("centred", "const", 900),
-                                                ("none", "const", 120)])
+@pytest.mark.parametrize("adv,hmix,max_iters", [("donor", "isop", 54), ("centred", "isop", 228), ("upwind3", "const", 140), ("centred", "const", 307),
+                                                ("none", "const", 60)])       # measured 41 / 175 / 107 / 236 / 46
 def test_operator_families_at_3_degrees(adv, hmix, max_iters):
     """Every advection / lateral-mixing family the reference's gen_A offers (src/gen_A.c:170-216), on the 3 degree x 60 grid
     of BASELINE configs[1]: the solve must meet 1e-10 on the oracle-recomputed residual within a bound that documents how
@@ -82,3 +85,12 @@ def test_operator_families_at_3_degrees(adv, hmix, max_iters):
     info = _solve(p, max_iters=3000)
     assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
     assert info["iters"] <= max_iters, info
+
+
+def test_centred_advection_at_1_degree():
+    """The reference's DEFAULT advection scheme (centred, src/gen_A.c:99) at the headline size, 1 degree x 60: the hardest family
+    for the low-order twin (cell Peclet numbers of 30 fully upwinded)."""
+    p = synth.generate(imt=320, jmt=384, km=60, adv="centred", hmix="isop", seed=0)
+    info = _solve(p, max_iters=2000)
+    assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
+    assert info["iters"] <= 410, info                           # round 2 measured 315
