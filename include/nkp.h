@@ -112,6 +112,8 @@ typedef struct nkp_tuning {
    int spmv_run;             /* NKP_SPMV_RUN (1): row blocks one workgroup walks */
    int spmv_wgs;             /* NKP_SPMV_WGS (256): workgroups per CU at most */
    /* ---- Krylov / distributed flavour / setup */
+   int rhs_batch;            /* NKP_RHS_BATCH (1): several right-hand sides of one call share the sweeps over the matrix and the
+                                hierarchy (nkp_solve_batch_device; same bits per column); 0 = one at a time */
    int precond_steps;        /* NKP_PRECOND_STEPS (0 = leave nkp_options.precond_steps) */
    int equil;                /* NKP_EQUIL (-1 = leave nkp_options.equil) */
    int dist_overlap;         /* NKP_DIST_OVERLAP (1): halo exchange behind the interior rows */
@@ -197,6 +199,16 @@ int nkp_create64 (nkp_solver **out, const nkp_options *opt, int64_t n, const int
  * <= max (1e-14, rtol / 100), else NKP_NOT_CONVERGED. */
 int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t ldb,
                double *berr, int *iters, double *relres);
+
+/* Several right-hand sides at once -- the reference's RHS loop (src/solve_ABglobal.c:370-409) with the tracers sharing every sweep
+ * over the matrix and the hierarchy: d_B / d_X hold nrhs vectors of n doubles on the solver's device, vector c at offset c * ldb
+ * (d_X may alias d_B).  Systems are solved in groups of up to four; each keeps its own FGMRES recurrence and stopping test, the
+ * operator and preconditioner applications of a Krylov step are one pass for the group.  Column c of the result has the bits
+ * nkp_solve_device gives for that right-hand side alone, iters[c] / relres[c] / berr[c] likewise; the return code is the worst of
+ * the columns'.  Needs K - 1 more sets of work vectors (kept for later calls).  Falls back to one at a time where the batched path
+ * does not apply (BiCGStab, row equilibration, chained cycles, the distributed flavour) or with nkp_tuning.rhs_batch = 0.
+ * nkp_solve with nrhs >= 2 takes the same path. */
+int nkp_solve_batch_device (nkp_solver *s, int nrhs, const void *d_B, void *d_X, int64_t ldb, double *berr, int *iters, double *relres);
 
 /* Same, with b and x already resident on the solver's device (x may alias b); x_inout is also
  * the initial guess when use_guess != 0. */

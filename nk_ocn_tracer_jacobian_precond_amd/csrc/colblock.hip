@@ -1136,6 +1136,106 @@ void colblock_apply_ldspack_kernel (const int *__restrict__ grp_nb, const int *_
    }
 }
 
+// The same kernel on TWO right-hand sides of a K-interleaved batch (batch.hip): lanes 0-31 run the columns on system k0, lanes
+// 32-63 the same columns on system k0 + 1 -- the half of the wave that idles in the single-vector kernel (and already loads
+// the same factors) does the second system, so the factor stream is read once per pair.  rhs / z are K-interleaved
+// (element (row, k) at row * K + k); K = 4 takes two launches (k0 = 0, 2).  Same operations per column => same bits.
+template <int P, int NCH>
+__global__ __launch_bounds__ (NKP_WAVE, 2)
+void colblock_apply_ldspack2_kernel (const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
+                                     const float *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
+                                     const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp, int K, int k0)
+{
+   extern __shared__ double lds[];
+   constexpr int gw = 32, CH = 16, STRIDE = NCH * CH + 1;
+   constexpr LdspSchedule<NCH, P * CH, (P + 1) * CH> S;
+   const int g = blockIdx.x + g_first;
+   const int lane = threadIdx.x;
+   const int ml = grp_maxlen[g];
+   const int nch = ml / CH, mlq = ml >> 2;
+   const int R0 = grp_row0[g];
+   const int cl = lane & (gw - 1);
+   const int s = col_slot[g * gw + cl], len = col_slot[(ngrp + g) * gw + cl];
+   const float4 *f4 = reinterpret_cast<const float4 *> (fac_t + grp_base[g]) + cl;
+#define LDSP_FWD_K0(t) (((t) < nch ? (t) : nch - 1) * CH)
+#define LDSP_BWD_K0(t) ((nch - 1 - (t) > 0 ? nch - 1 - (t) : 0) * CH)
+   PackChunk<P> F[NCH], Bq[NCH];
+#pragma unroll
+   for (int t = 0; t < NCH; t++)
+      if (t < S.f_upfront) ldsp_load_fwd<P> (F[t], f4, mlq, LDSP_FWD_K0 (t), gw);
+#pragma unroll
+   for (int t = 0; t < NCH; t++)
+      if (t < S.b_upfront) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+#pragma unroll
+   for (int c0 = 0; c0 < gw; c0 += 8) {
+      double2 t[8], t2[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         const int sc = __builtin_amdgcn_readlane (s, c0 + u), lc = __builtin_amdgcn_readlane (len, c0 + u);
+         t[u] = (lane < lc) ? *reinterpret_cast<const double2 *> (rhs + ((int64_t) R0 + sc + lane) * K + k0) : make_double2 (0.0, 0.0);
+         if (NCH > 4) t2[u] = (lane + NKP_WAVE < lc) ? *reinterpret_cast<const double2 *> (rhs + ((int64_t) R0 + sc + lane + NKP_WAVE) * K + k0) : make_double2 (0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         lds[(c0 + u) * STRIDE + lane] = t[u].x;
+         lds[(gw + c0 + u) * STRIDE + lane] = t[u].y;
+         if (NCH > 4 && lane < STRIDE - 1 - NKP_WAVE) {
+            lds[(c0 + u) * STRIDE + lane + NKP_WAVE] = t2[u].x;
+            lds[(gw + c0 + u) * STRIDE + lane + NKP_WAVE] = t2[u].y;
+         }
+      }
+   }
+   __syncthreads ();
+   {
+      double *col = lds + lane * STRIDE;                    // slot lane = (system half, column)
+      double w[P];
+#pragma unroll
+      for (int q = 0; q < P; q++) w[q] = 0.0;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+         if (c < nch) ldsp_step_fwd<P> (F[c], col, c * CH, w);
+#pragma unroll
+         for (int t = 0; t < NCH; t++)
+            if (t >= (c ? S.f_after[c - 1] : S.f_upfront) && t < S.f_after[c]) ldsp_load_fwd<P> (F[t], f4, mlq, LDSP_FWD_K0 (t), gw);
+#pragma unroll
+         for (int t = 0; t < NCH; t++)
+            if (t >= (c ? S.b_after_f[c - 1] : S.b_upfront) && t < S.b_after_f[c]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+      }
+#pragma unroll
+      for (int q = 0; q < P; q++) w[q] = 0.0;
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+         if (j < nch) ldsp_step_bwd<P> (Bq[j], col, (nch - 1 - j) * CH, w);
+#pragma unroll
+         for (int t = 0; t < NCH; t++)
+            if (t >= (j ? S.b_after_b[j - 1] : S.b_after_f[NCH - 1]) && t < S.b_after_b[j]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+      }
+   }
+#undef LDSP_FWD_K0
+#undef LDSP_BWD_K0
+   __syncthreads ();
+#pragma unroll
+   for (int c0 = 0; c0 < gw; c0 += 8) {
+      double2 t[8], t2[8];
+      int sc[8], lc[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         sc[u] = __builtin_amdgcn_readlane (s, c0 + u);
+         lc[u] = __builtin_amdgcn_readlane (len, c0 + u);
+         t[u] = (accumulate && lane < lc[u]) ? *reinterpret_cast<const double2 *> (z + ((int64_t) R0 + sc[u] + lane) * K + k0) : make_double2 (0.0, 0.0);
+         if (NCH > 4) t2[u] = (accumulate && lane + NKP_WAVE < lc[u]) ? *reinterpret_cast<const double2 *> (z + ((int64_t) R0 + sc[u] + lane + NKP_WAVE) * K + k0) : make_double2 (0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+         if (lane < lc[u])
+            *reinterpret_cast<double2 *> (z + ((int64_t) R0 + sc[u] + lane) * K + k0) = make_double2 (t[u].x + lds[(c0 + u) * STRIDE + lane], t[u].y + lds[(gw + c0 + u) * STRIDE + lane]);
+         if (NCH > 4 && lane + NKP_WAVE < lc[u])
+            *reinterpret_cast<double2 *> (z + ((int64_t) R0 + sc[u] + lane + NKP_WAVE) * K + k0) =
+               make_double2 (t2[u].x + lds[(c0 + u) * STRIDE + lane + NKP_WAVE], t2[u].y + lds[(gw + c0 + u) * STRIDE + lane + NKP_WAVE]);
+      }
+   }
+}
+
 template <class T>
 static int up (T **dst, const std::vector<T> &src, size_t *bytes)
 {
@@ -1696,4 +1796,158 @@ void launch_colblock_apply_lanes (const ColBlocksDev &B, int g0, int g1, const d
 #undef LANES_LAUNCH
 #undef LANES_LAUNCH2
 #undef LANES_LAUNCH_W3
+}
+
+// FOUR right-hand sides in one launch: a wave takes 16 of a group's 32 columns (block 2 g + h = half h of group g) for all four
+// systems -- lane = system * 16 + column.  The factors are read once for the four systems (the 16 lanes of every system address
+// the same 256 bytes), the staging moves whole 32-byte rows of the interleaved vectors.  The two-system kernel above takes two
+// launches for K = 4 and its 33 KB of LDS per wave leave a colour's 1469 waves in 1.4 rounds of 4 per CU: 53 us per launch
+// at 1 degree, slower per system than the single-vector kernel; here the same LDS holds 4 x 16 slots and the waves are twice as many.
+template <int P, int NCH>
+__global__ __launch_bounds__ (NKP_WAVE, 2)
+void colblock_apply_ldspack4_kernel (const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
+                                     const float *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
+                                     const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp)
+{
+   extern __shared__ double lds[];
+   constexpr int gw = 32, hw = 16, K = 4, CH = 16, STRIDE = NCH * CH + 1;
+   constexpr LdspSchedule<NCH, P * CH, (P + 1) * CH> S;
+   const int g = (int) (blockIdx.x >> 1) + g_first, half = blockIdx.x & 1;
+   const int lane = threadIdx.x;
+   const int ml = grp_maxlen[g];
+   const int nch = ml / CH, mlq = ml >> 2;
+   const int R0 = grp_row0[g];
+   const int cl = half * hw + (lane & (hw - 1));             // this lane's column within the group
+   const int s = col_slot[g * gw + cl], len = col_slot[(ngrp + g) * gw + cl];
+   const float4 *f4 = reinterpret_cast<const float4 *> (fac_t + grp_base[g]) + cl;
+#define LDSP_FWD_K0(t) (((t) < nch ? (t) : nch - 1) * CH)
+#define LDSP_BWD_K0(t) ((nch - 1 - (t) > 0 ? nch - 1 - (t) : 0) * CH)
+   PackChunk<P> F[NCH], Bq[NCH];
+#pragma unroll
+   for (int t = 0; t < NCH; t++)
+      if (t < S.f_upfront) ldsp_load_fwd<P> (F[t], f4, mlq, LDSP_FWD_K0 (t), gw);
+#pragma unroll
+   for (int t = 0; t < NCH; t++)
+      if (t < S.b_upfront) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+   // slot (system q, column c) at (q * 16 + c) * STRIDE; one column per step, lane = row, the row's four values in two 16-byte loads
+#pragma unroll
+   for (int c0 = 0; c0 < hw; c0 += 4) {
+      double2 ta[4], tb[4], ua[4], ub[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         const int sc = __builtin_amdgcn_readlane (s, c0 + u), lc = __builtin_amdgcn_readlane (len, c0 + u);
+         const double *src = rhs + ((int64_t) R0 + sc + lane) * K;
+         ta[u] = (lane < lc) ? *reinterpret_cast<const double2 *> (src) : make_double2 (0.0, 0.0);
+         tb[u] = (lane < lc) ? *reinterpret_cast<const double2 *> (src + 2) : make_double2 (0.0, 0.0);
+         if (NCH > 4) {
+            ua[u] = (lane + NKP_WAVE < lc) ? *reinterpret_cast<const double2 *> (src + (int64_t) NKP_WAVE * K) : make_double2 (0.0, 0.0);
+            ub[u] = (lane + NKP_WAVE < lc) ? *reinterpret_cast<const double2 *> (src + (int64_t) NKP_WAVE * K + 2) : make_double2 (0.0, 0.0);
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         lds[(0 * hw + c0 + u) * STRIDE + lane] = ta[u].x;
+         lds[(1 * hw + c0 + u) * STRIDE + lane] = ta[u].y;
+         lds[(2 * hw + c0 + u) * STRIDE + lane] = tb[u].x;
+         lds[(3 * hw + c0 + u) * STRIDE + lane] = tb[u].y;
+         if (NCH > 4 && lane < STRIDE - 1 - NKP_WAVE) {
+            lds[(0 * hw + c0 + u) * STRIDE + lane + NKP_WAVE] = ua[u].x;
+            lds[(1 * hw + c0 + u) * STRIDE + lane + NKP_WAVE] = ua[u].y;
+            lds[(2 * hw + c0 + u) * STRIDE + lane + NKP_WAVE] = ub[u].x;
+            lds[(3 * hw + c0 + u) * STRIDE + lane + NKP_WAVE] = ub[u].y;
+         }
+      }
+   }
+   __syncthreads ();
+   {
+      double *col = lds + lane * STRIDE;                    // slot lane = (system, column)
+      double w[P];
+#pragma unroll
+      for (int q = 0; q < P; q++) w[q] = 0.0;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+         if (c < nch) ldsp_step_fwd<P> (F[c], col, c * CH, w);
+#pragma unroll
+         for (int t = 0; t < NCH; t++)
+            if (t >= (c ? S.f_after[c - 1] : S.f_upfront) && t < S.f_after[c]) ldsp_load_fwd<P> (F[t], f4, mlq, LDSP_FWD_K0 (t), gw);
+#pragma unroll
+         for (int t = 0; t < NCH; t++)
+            if (t >= (c ? S.b_after_f[c - 1] : S.b_upfront) && t < S.b_after_f[c]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+      }
+#pragma unroll
+      for (int q = 0; q < P; q++) w[q] = 0.0;
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+         if (j < nch) ldsp_step_bwd<P> (Bq[j], col, (nch - 1 - j) * CH, w);
+#pragma unroll
+         for (int t = 0; t < NCH; t++)
+            if (t >= (j ? S.b_after_b[j - 1] : S.b_after_f[NCH - 1]) && t < S.b_after_b[j]) ldsp_load_bwd<P> (Bq[t], f4, mlq, LDSP_BWD_K0 (t), gw);
+      }
+   }
+#undef LDSP_FWD_K0
+#undef LDSP_BWD_K0
+   __syncthreads ();
+#pragma unroll
+   for (int c0 = 0; c0 < hw; c0 += 4) {
+      double2 ta[4], tb[4], ua[4], ub[4];
+      int sc[4], lc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         sc[u] = __builtin_amdgcn_readlane (s, c0 + u);
+         lc[u] = __builtin_amdgcn_readlane (len, c0 + u);
+         const double *src = z + ((int64_t) R0 + sc[u] + lane) * K;
+         ta[u] = (accumulate && lane < lc[u]) ? *reinterpret_cast<const double2 *> (src) : make_double2 (0.0, 0.0);
+         tb[u] = (accumulate && lane < lc[u]) ? *reinterpret_cast<const double2 *> (src + 2) : make_double2 (0.0, 0.0);
+         if (NCH > 4) {
+            ua[u] = (accumulate && lane + NKP_WAVE < lc[u]) ? *reinterpret_cast<const double2 *> (src + (int64_t) NKP_WAVE * K) : make_double2 (0.0, 0.0);
+            ub[u] = (accumulate && lane + NKP_WAVE < lc[u]) ? *reinterpret_cast<const double2 *> (src + (int64_t) NKP_WAVE * K + 2) : make_double2 (0.0, 0.0);
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+         double *dst = z + ((int64_t) R0 + sc[u] + lane) * K;
+         if (lane < lc[u]) {
+            *reinterpret_cast<double2 *> (dst) = make_double2 (ta[u].x + lds[(0 * hw + c0 + u) * STRIDE + lane], ta[u].y + lds[(1 * hw + c0 + u) * STRIDE + lane]);
+            *reinterpret_cast<double2 *> (dst + 2) = make_double2 (tb[u].x + lds[(2 * hw + c0 + u) * STRIDE + lane], tb[u].y + lds[(3 * hw + c0 + u) * STRIDE + lane]);
+         }
+         if (NCH > 4 && lane + NKP_WAVE < lc[u]) {
+            double *d2 = dst + (int64_t) NKP_WAVE * K;
+            *reinterpret_cast<double2 *> (d2) = make_double2 (ua[u].x + lds[(0 * hw + c0 + u) * STRIDE + lane + NKP_WAVE], ua[u].y + lds[(1 * hw + c0 + u) * STRIDE + lane + NKP_WAVE]);
+            *reinterpret_cast<double2 *> (d2 + 2) = make_double2 (ub[u].x + lds[(2 * hw + c0 + u) * STRIDE + lane + NKP_WAVE], ub[u].y + lds[(3 * hw + c0 + u) * STRIDE + lane + NKP_WAVE]);
+         }
+      }
+   }
+}
+
+// groups [g0, g1) of a level whose layout is the packed one (B.ldsres == 2), K-interleaved right-hand sides: K / 2 launches of the
+// two-system kernel.  Returns non-zero (nothing launched) for any other layout: the caller then uses the wave-per-column batch kernel.
+int launch_colblock_apply_lanes_batch (int K, const ColBlocksDev &B, int g0, int g1, const double *r, double *z, int accumulate, hipStream_t st)
+{
+   if (B.ldsres != 2 || !B.fac_tf) return 1;
+   if (g1 <= g0) return 0;
+   const int nch = B.max_len <= 64 ? 4 : 5;
+   const size_t lds = (size_t) 64 * (size_t) (nch * NKP_LDSRES_CH + 1) * sizeof (double);
+   if (K == 4) {
+      // one launch for the four systems, two waves (16 columns each) per group
+#define LDSP4_LAUNCH(PP) do { if (nch == 4) hipLaunchKernelGGL ((colblock_apply_ldspack4_kernel<PP, 4>), dim3 (2 * (g1 - g0)), dim3 (NKP_WAVE), lds, st, B.grp_maxlen, B.grp_base, g0, \
+                                                                 B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp);                                                \
+                              else hipLaunchKernelGGL ((colblock_apply_ldspack4_kernel<PP, 5>), dim3 (2 * (g1 - g0)), dim3 (NKP_WAVE), lds, st, B.grp_maxlen, B.grp_base, g0,  \
+                                                       B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp); } while (0)
+      if (B.P == 1) LDSP4_LAUNCH (1);
+      else if (B.P == 2) LDSP4_LAUNCH (2);
+      else LDSP4_LAUNCH (4);
+#undef LDSP4_LAUNCH
+      return 0;
+   }
+   for (int k0 = 0; k0 < K; k0 += 2) {
+#define LDSP2_LAUNCH(PP) do { if (nch == 4) hipLaunchKernelGGL ((colblock_apply_ldspack2_kernel<PP, 4>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.grp_maxlen, B.grp_base, g0, \
+                                                                 B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp, K, k0);                                         \
+                              else hipLaunchKernelGGL ((colblock_apply_ldspack2_kernel<PP, 5>), dim3 (g1 - g0), dim3 (NKP_WAVE), lds, st, B.grp_maxlen, B.grp_base, g0,       \
+                                                       B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp, K, k0); } while (0)
+      if (B.P == 1) LDSP2_LAUNCH (1);
+      else if (B.P == 2) LDSP2_LAUNCH (2);
+      else LDSP2_LAUNCH (4);
+#undef LDSP2_LAUNCH
+   }
+   return 0;
 }

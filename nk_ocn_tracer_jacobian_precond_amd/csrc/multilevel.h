@@ -22,6 +22,11 @@ struct MlLevel {
    // of colour c's rows; the level's x is coherent (one buffer) whenever cur[0] == cur[1]
    double *x2 = nullptr;
    int cur[2] = { 0, 0 };
+   // K interleaved right-hand sides (batch.hip): the level's vectors once more, K times as long (allocated on first use)
+   double *bx = nullptr, *bx2 = nullptr, *bb = nullptr, *br = nullptr;
+   int bcur[2] = { 0, 0 };
+   double *bxbuf (int k) { return k ? bx2 : bx; }
+   double *bxnow () { return bxbuf (bcur[0]); }
    double *xbuf (int k) { return k ? x2 : x; }
    double *xnow () { return xbuf (cur[0]); }      // valid when coherent
 };
@@ -42,6 +47,7 @@ struct MlHierarchy {
    size_t device_bytes = 0;
    double setup_seconds = 0.0;  // wall time of ml_setup
    int levels_on_device = 0;    // levels whose operator was built by the kernels of mlsetup.hip
+   int batch_K = 0;             // the level vectors of ml_apply_batch exist for this many right-hand sides
 };
 
 // returns 0, or a negative nkp error code with a message in err
@@ -52,6 +58,10 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 void ml_free (MlHierarchy &H);
 // z = V-cycle(r) in the ORIGINAL row order
 void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st);
+// the same cycle on K interleaved right-hand sides (r, z: n * K doubles, element (row, k) at row * K + k; K = 2 or 4); every
+// column gets the bits ml_apply gives it alone.  ml_batch_prepare allocates the level vectors (0, or -2 = out of device memory).
+int ml_batch_prepare (MlHierarchy &H, int K);
+void ml_apply_batch (MlHierarchy &H, int K, const double *r, double *z, hipStream_t st);
 // measurement helpers: launch one piece of a level-0 half sweep (0 residual rows, 1 column solves); compulsory HBM bytes of
 // that piece or of the whole cycle (2)
 void ml_time_piece (MlHierarchy &H, int which, hipStream_t st);

@@ -1472,7 +1472,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 void ml_free (MlHierarchy &H)
 {
    for (MlLevel &V : H.lev) {
-      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.valf, V.B.fac_tf, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.grp_row0, V.B.col_slot, V.B.fac_t, V.B.gs_rb_ptr, V.B.gs_rb, V.cmap, V.rptr, V.ridx, V.x, V.x2, V.b, V.r };
+      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.valf, V.B.fac_tf, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.grp_row0, V.B.col_slot, V.B.fac_t, V.B.gs_rb_ptr, V.B.gs_rb, V.cmap, V.rptr, V.ridx, V.x, V.x2, V.b, V.r, V.bx, V.bx2, V.bb, V.br };
       for (void *p : ptrs)
          if (p) (void) hipFree (p);
    }
@@ -1574,6 +1574,97 @@ void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st)
    launch_gather (H.perm0, r, V.b, V.n, st);
    ml_cycle (H, 0, st);
    launch_scatter (H.perm0, V.xnow (), z, V.n, st);
+}
+
+// ================================================================ the cycle on K interleaved right-hand sides
+int ml_batch_prepare (MlHierarchy &H, int K)
+{
+   if (K != 2 && K != 4) return -1;
+   if (H.batch_K >= K) return 0;
+   for (MlLevel &V : H.lev) {
+      for (double **p : { &V.bx, &V.bx2, &V.bb, &V.br }) {
+         if (*p) { (void) hipFree (*p); *p = nullptr; }
+         const size_t bytes = (size_t) (V.n ? V.n : 1) * (size_t) K * sizeof (double);
+         if (hipMalloc ((void **) p, bytes) != hipSuccess) return -2;
+         if (hipMemset (*p, 0, bytes) != hipSuccess) return -2;
+         H.device_bytes += bytes;
+      }
+   }
+   H.batch_K = K;
+   return 0;
+}
+
+static void column_solves_batch (const MlHierarchy &H, MlLevel &V, int K, int c, const double *rhs, double *x, int accumulate, hipStream_t st)
+{
+   // the packed lane layout has a two-system kernel; every other level takes the wave-per-column kernel (which reads the
+   // f64 factors and rounds them like the f32 layouts store them: same values)
+   if (V.wave_columns || launch_colblock_apply_lanes_batch (K, V.B, V.color_grp[c], V.color_grp[c + 1], rhs, x, accumulate, st) != 0)
+      launch_colblock_apply_wave_batch (K, V.B, V.color_blk[c], V.color_blk[c + 1], rhs, x, accumulate, H.f32, st);
+}
+
+static void gs_half_batch (const MlHierarchy &H, MlLevel &V, int K, int c, hipStream_t st)
+{
+   if (V.wave_fused) {
+      const int out = (V.bcur[0] != V.bcur[1]) ? V.bcur[1 - c] : 1 - V.bcur[c];
+      launch_gs_wave_batch (K, V.L, V.B, V.color_blk[c], V.color_blk[c + 1], V.bxbuf (V.bcur[0]), V.bxbuf (V.bcur[1]), (int) V.rows0, V.bb, V.bxbuf (out), H.f32, st);
+      V.bcur[c] = out;
+      return;
+   }
+   launch_csr_spmv_batch (K, V.L, V.color_rb[c], V.color_rb[c + 1], V.bx, V.br, V.bb, 1, st);
+   column_solves_batch (H, V, K, c, V.br, V.bx, 1, st);
+}
+
+static void ml_cycle_batch (MlHierarchy &H, int K, int l, hipStream_t st)
+{
+   MlLevel &V = H.lev[l];
+   const int64_t nk = V.n * K;
+   V.bcur[0] = V.bcur[1] = 0;
+   if (l == (int) H.lev.size () - 1) {
+      if (H.coarse_inv) {
+         launch_dense_matvec_batch (K, H.coarse_inv, V.bb, V.bx, (int) V.n, st);
+         return;
+      }
+      const int sweeps = H.tune->ml_coarsest_sweeps > 0 ? H.tune->ml_coarsest_sweeps : 30;
+      launch_fill (V.bx, 0.0, nk, st);
+      column_solves_batch (H, V, K, 0, V.bb, V.bx, 0, st);
+      launch_csr_spmv_batch (K, V.L, V.color_rb[1], V.color_rb[2], V.bx, V.br, V.bb, 1, st);
+      column_solves_batch (H, V, K, 1, V.br, V.bx, 1, st);
+      for (int s = 1; s < sweeps; s++)
+         for (int step = 0; step < 2; step++) {
+            const int c = (s & 1) ? 1 - step : step;
+            launch_csr_spmv_batch (K, V.L, V.color_rb[c], V.color_rb[c + 1], V.bx, V.br, V.bb, 1, st);
+            column_solves_batch (H, V, K, c, V.br, V.bx, 1, st);
+         }
+      return;
+   }
+   launch_fill (V.bx, 0.0, nk, st);
+   if (V.wave_fused) {
+      column_solves_batch (H, V, K, 0, V.bb, V.bx2, 0, st);
+      V.bcur[0] = 1;
+      gs_half_batch (H, V, K, 1, st);
+   } else {
+      column_solves_batch (H, V, K, 0, V.bb, V.bx, 0, st);
+      gs_half_batch (H, V, K, 1, st);
+   }
+   const int nu = (l >= H.coarse_from) ? H.nu_coarse : H.nu;
+   for (int s = 1; s < nu; s++) { gs_half_batch (H, V, K, 0, st); gs_half_batch (H, V, K, 1, st); }
+   MlLevel &C = H.lev[l + 1];
+   const int gamma = (l >= H.gamma_from && l < H.gamma_to) ? 2 : 1;
+   for (int g = 0; g < gamma; g++) {
+      launch_csr_spmv_batch (K, V.L, 0, V.L.nrowblk, V.bxnow (), V.br, V.bb, 1, st);
+      launch_restrict_sum_batch (K, V.rptr, V.ridx, V.br, C.bb, V.nc, st);
+      ml_cycle_batch (H, K, l + 1, st);
+      launch_prolong_add_batch (K, V.cmap, C.bxnow (), V.bxnow (), V.n, H.omega, st);
+   }
+   for (int s = 0; s < nu; s++) { gs_half_batch (H, V, K, 1, st); gs_half_batch (H, V, K, 0, st); }
+}
+
+void ml_apply_batch (MlHierarchy &H, int K, const double *r, double *z, hipStream_t st)
+{
+   MlLevel &V = H.lev[0];
+   launch_gather_batch (K, H.perm0, r, V.bb, V.n, st);
+   ml_cycle_batch (H, K, 0, st);
+   launch_scatter_batch (K, H.perm0, V.bxnow (), z, V.n, st);
 }
 
 // ================================================================ measurement helpers (bench.py, probes)

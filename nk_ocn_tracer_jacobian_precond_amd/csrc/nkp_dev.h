@@ -157,3 +157,20 @@ void launch_gather (const int *perm, const double *in, double *out, int64_t n, h
 void launch_scatter (const int *perm, const double *in, double *out, int64_t n, hipStream_t st);
 // y = Minv x, dense row-major n x n (coarsest level)
 void launch_dense_matvec (const double *Minv, const double *x, double *y, int n, hipStream_t st);
+
+// ---------------------------------------------------------------- K interleaved right-hand sides (batch.hip; X[i * K + k], K = 2 or 4)
+void launch_interleave (int K, const double *const *src /* K pointers, NULL = zeros */, double *X, int64_t n, hipStream_t st);
+void launch_deinterleave (int K, const double *X, double *const *dst /* K pointers, NULL = skip */, int64_t n, hipStream_t st);
+// row blocks [rb0, rb1) of A: y = A x (mode 0) or y = b - A x (mode 1) on K columns
+void launch_csr_spmv_batch (int K, const CsrDev &A, int rb0, int rb1, const double *x, double *y, const double *b, int mode, hipStream_t st);
+void launch_restrict_sum_batch (int K, const int *rptr, const int *ridx, const double *fine, double *coarse, int64_t nc, hipStream_t st);
+void launch_prolong_add_batch (int K, const int *cmap, const double *coarse, double *fine, int64_t nf, double omega, hipStream_t st);
+void launch_gather_batch (int K, const int *perm, const double *in, double *out, int64_t n, hipStream_t st);
+void launch_scatter_batch (int K, const int *perm, const double *in, double *out, int64_t n, hipStream_t st);
+void launch_dense_matvec_batch (int K, const double *Minv, const double *x, double *y, int n, hipStream_t st);
+// water-column solves of blocks [b0, b1), one column per wave / the fused half sweep, K columns
+void launch_colblock_apply_wave_batch (int K, const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, int r32, hipStream_t st);
+void launch_gs_wave_batch (int K, const CsrDev &L, const ColBlocksDev &B, int b0, int b1, const double *xa, const double *xb, int split, const double *b, double *xout,
+                           int r32, hipStream_t st);
+// groups [g0, g1) with the packed lane layout (colblock.hip); non-zero = layout not served, use the wave kernel
+int launch_colblock_apply_lanes_batch (int K, const ColBlocksDev &B, int g0, int g1, const double *r, double *z, int accumulate, hipStream_t st);

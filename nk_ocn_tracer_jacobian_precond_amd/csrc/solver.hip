@@ -86,7 +86,7 @@ static void builtin_tuning (nkp_tuning *t)
    t->col_ldsres = 2; t->col_stream = 1; t->col_stream_min = -1; t->col_stream_gw = 32; t->col_wave_max = 8192; t->col_w3 = 1;
    t->col_group = 8; t->col_pipe_min = 0; t->col_ldsres_early = 0; t->col_ldsres_packed = 1;
    t->spmv_variant = 4; t->spmv_compress = 0; t->spmv_pipe_min = 1024; t->spmv_run = 1; t->spmv_wgs = 256;
-   t->precond_steps = 0; t->equil = -1; t->dist_overlap = 1; t->dist_ras = 1; t->force_dist = 0; t->setup_threads = 0; t->plan_times = 0;
+   t->rhs_batch = 1; t->precond_steps = 0; t->equil = -1; t->dist_overlap = 1; t->dist_ras = 1; t->force_dist = 0; t->setup_threads = 0; t->plan_times = 0;
    t->ml_drop_intertracer = 0;
 }
 
@@ -121,6 +121,7 @@ extern "C" int nkp_default_tuning (nkp_tuning *t)
    ENV_INT ("NKP_COLPIPE_MIN", col_pipe_min); ENV_FLAG ("NKP_LDSRES_EARLY", col_ldsres_early); ENV_FLAG ("NKP_COL_PACKED", col_ldsres_packed);
    ENV_INT ("NKP_SPMV_VARIANT", spmv_variant); ENV_FLAG ("NKP_SPMV_COMPRESS", spmv_compress); ENV_INT ("NKP_SPMV_PIPE_MIN", spmv_pipe_min);
    ENV_POS ("NKP_SPMV_RUN", spmv_run); ENV_POS ("NKP_SPMV_WGS", spmv_wgs);
+   ENV_FLAG ("NKP_RHS_BATCH", rhs_batch);
    ENV_POS ("NKP_PRECOND_STEPS", precond_steps); ENV_FLAG ("NKP_EQUIL", equil);
    ENV_FLAG ("NKP_DIST_OVERLAP", dist_overlap); ENV_FLAG ("NKP_DIST_RAS", dist_ras);
    if (getenv ("NKP_FORCE_DIST")) t->force_dist = 1;
@@ -198,6 +199,11 @@ struct nkp_solver {
    double *dscal = nullptr;         // device scalars: h[m+2] | h2[m+2] | misc[16] | ycoef[m+1]
    double *hpin = nullptr;          // pinned host mirror
    int *dint = nullptr;             // device ints
+   // K right-hand sides at once (nkp_solve_batch_device): K - 1 more sets of work vectors (clones sharing this solver's stream)
+   // and three K-interleaved vectors around the batched operator / cycle application
+   std::vector<nkp_solver *> batch_members;
+   double *bvin = nullptr, *bz = nullptr, *bw = nullptr;
+   int batch_K = 0;
    size_t device_bytes = 0;
    double create_seconds = 0.0;     // wall time of nkp_create
    double *h_dev () { return dscal; }
@@ -235,6 +241,10 @@ static void solver_free (nkp_solver *s)
       delete s;
       return;
    }
+   for (nkp_solver *c : s->batch_members) solver_free (c);
+   s->batch_members.clear ();
+   for (double *p : { s->bvin, s->bz, s->bw })
+      if (p) (void) hipFree (p);
    void *ptrs[] = { s->A.rowptr, s->A.colind, s->A.val, s->A.rowblk, s->A.codes, s->A.dict, s->A.dict_ptr, s->B.blk_start, s->B.fac, s->B.grp_b0, s->B.grp_nb, s->B.grp_maxlen, s->B.grp_base, s->B.grp_row0, s->B.col_slot, s->B.fac_t, s->B.gs_rb_ptr, s->B.gs_rb, s->V, s->vcur, s->Z, s->w, s->r,
                     s->x, s->b, s->t1, s->t2, s->p1, s->p2, s->partial, s->dscal, s->dint, s->rscale, s->rinv, s->eqtmp };
    for (void *p : ptrs)
@@ -708,6 +718,7 @@ extern "C" int nkp_set_stream (nkp_solver *s, void *hip_stream)
    // caller switched streams), so work enqueued here stays ordered with the caller's own kernels
    s->stream = (hipStream_t) hip_stream;
    s->own_stream = false;
+   for (nkp_solver *c : s->batch_members) c->stream = s->stream;      // the members of a batch share the solver's stream
    return NKP_OK;
 }
 
@@ -755,9 +766,10 @@ static int dot_host (nkp_solver *s, const double *x, const double *y, double *ou
    return NKP_OK;
 }
 
-// one Arnoldi step on the device: z_j = M^-1 v_j, w = A z_j, orthogonalise against V[0..j],
-// v_{j+1} = w/||w||; leaves the Hessenberg column h[0..j+1] in s->h_dev()
-static void arnoldi_step_device (nkp_solver *s, int j)
+// one Arnoldi step on the device in two halves: (1) z_j = M^-1 v_j, w = A z_j; (2) orthogonalise w against V[0..j],
+// v_{j+1} = w / ||w||, which leaves the Hessenberg column h[0..j+1] in s->h_dev().  The batched driver below replaces (1) by
+// ONE application of the cycle and of A to K interleaved vectors and runs (2) per system.
+static void arnoldi_apply (nkp_solver *s, int j)
 {
    const int64_t ld = s->ld;
    double *zj = s->Z + (int64_t) j * ld;
@@ -772,6 +784,11 @@ static void arnoldi_step_device (nkp_solver *s, int j)
       apply_precond (s, vj, zj);
       spmv_op (s, zj, s->w, nullptr, 0);
    }
+}
+
+static void arnoldi_orthogonalise (nkp_solver *s, int j)
+{
+   const int64_t ld = s->ld;
    launch_multi_dot (s->V, s->vf32, ld, j + 1, s->w, s->n, s->partial, s->h_dev (), s->stream);
    allreduce_dev (s, s->h_dev (), j + 2, 0);                 // one allreduce per Gram-Schmidt pass
    launch_update_w (s->V, s->vf32, ld, j + 1, s->h_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
@@ -789,126 +806,187 @@ static void arnoldi_step_device (nkp_solver *s, int j)
    else launch_scale_to (s->w, s->misc_dev () + 1, s->V + (int64_t) (j + 1) * ld, nullptr, s->n, s->stream);
 }
 
-static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
+static void arnoldi_step_device (nkp_solver *s, int j)
+{
+   arnoldi_apply (s, j);
+   arnoldi_orthogonalise (s, j);
+}
+
+// ---------------------------------------------------------------- FGMRES as a state machine
+// One right-hand side's restarted FGMRES, cut at the points where the host looks at device results, so that the same code
+// drives one system (fgmres) or K of them in lockstep around batched operator applications (fgmres_batch).
+//
+// The recurrence's residual estimate assumes an orthonormal basis; with one Gram-Schmidt pass it can run ahead of the true
+// residual.  When a cycle stops on the estimate and the true residual disagrees, the next cycle aims lower by the observed
+// factor (inner_scale).  Attainable-accuracy guard: three such cycles in a row that gain less than 30 % mean rounding has
+// decoupled the two for good, and the iteration is stopped instead of spinning to max_iters.
+struct FgmresState {
+   std::vector<double> H, cs, sn, g, y;
+   double bnorm = 0.0, target = 0.0, relres = 0.0;
+   double beta = 0.0, beta_prev = 0.0, est_at_exit = 0.0, inner_scale = 1.0, beta_it = 0.0, target_it = 0.0;
+   int its = 0, status = NKP_NOT_CONVERGED, stalled_cycles = 0;
+   int j = 0;                              // columns of the running restart cycle
+   bool cycle_ended_on_estimate = false;
+   bool finished = false;                  // the solve is over (status says how)
+   bool breakdown_in_cycle = false;
+};
+
+// ||b||, the trivial case b = 0; returns a negative code on failure
+static int fg_begin (nkp_solver *s, FgmresState &F)
 {
    const int m = s->m;
-   const int64_t n = s->n, ld = s->ld;
-   hipStream_t st = s->stream;
-   std::vector<double> H ((size_t) (m + 1) * m, 0.0), cs (m), sn (m), g (m + 1), y (m);
+   F = FgmresState ();
+   F.H.assign ((size_t) (m + 1) * m, 0.0);
+   F.cs.assign (m, 0.0); F.sn.assign (m, 0.0); F.g.assign (m + 1, 0.0); F.y.assign (m, 0.0);
    double bnorm2 = 0.0;
    int rc = dot_host (s, s->b, s->b, &bnorm2);
    if (rc) return rc;
-   const double bnorm = sqrt (bnorm2);
-   int its = 0;
-   double relres = 0.0;
-   if (!(bnorm > 0.0)) {         // b == 0 -> x = 0
-      launch_fill (s->x, 0.0, n, st);
-      *iters_out = 0;
-      *relres_out = 0.0;
-      return NKP_OK;
-   }
-   const double target = fmax (s->opt.rtol * bnorm, s->opt.atol);
-   int status = NKP_NOT_CONVERGED;
-   // The recurrence's residual estimate assumes an orthonormal basis; with one Gram-Schmidt pass it can
-   // run ahead of the true residual.  When a cycle stops on the estimate and the true residual disagrees,
-   // the next cycle aims lower by the observed factor (inner_scale).  Attainable-accuracy guard: three such
-   // cycles in a row that gain less than 30 % mean rounding has decoupled the two for good, and the
-   // iteration is stopped instead of spinning to max_iters.
-   bool cycle_ended_on_estimate = false;
-   double beta_prev = 0.0, est_at_exit = 0.0, inner_scale = 1.0;
-   int stalled_cycles = 0;
+   F.bnorm = sqrt (bnorm2);
    s->stagnated = false;
    s->steps_now = s->precond_steps;      // the run-time guard below lowers it for this solve only
-   for (;;) {
-      // true residual (unscaled: the stopping test is ||b - A x||_2 <= rtol ||b||_2 whatever norm the iteration minimises)
-      spmv_op (s, s->x, s->r, s->b, 1);
+   if (!(F.bnorm > 0.0)) {         // b == 0 -> x = 0
+      launch_fill (s->x, 0.0, s->n, s->stream);
+      F.finished = true;
+      F.status = NKP_OK;
+      F.relres = 0.0;
+      return NKP_OK;
+   }
+   F.target = fmax (s->opt.rtol * F.bnorm, s->opt.atol);
+   return NKP_OK;
+}
+
+// true residual, verdict, start vector of the next restart cycle.  After it either F.finished, or v_0 is in place (F.j = 0).
+static int fg_restart (nkp_solver *s, FgmresState &F)
+{
+   hipStream_t st = s->stream;
+   const int64_t n = s->n;
+   int rc;
+   // true residual (unscaled: the stopping test is ||b - A x||_2 <= rtol ||b||_2 whatever norm the iteration minimises)
+   spmv_op (s, s->x, s->r, s->b, 1);
+   double r2 = 0.0;
+   if ((rc = dot_host (s, s->r, s->r, &r2))) return rc;
+   const double beta = sqrt (r2);
+   F.beta = beta;
+   F.relres = beta / F.bnorm;
+   msg (s, 2, "fgmres: its = %d, true relres = %.3e\n", F.its, F.relres);
+   if (s->comm_failed) return fail (NKP_ECOMM, "nkp_solve: a collective of the distributed solve failed");
+   if (!(beta == beta)) { F.status = NKP_BREAKDOWN; F.finished = true; return NKP_OK; }
+   if (beta <= F.target) { F.status = NKP_OK; F.finished = true; return NKP_OK; }
+   if (F.its >= s->opt.max_iters) { F.status = NKP_NOT_CONVERGED; F.finished = true; return NKP_OK; }
+   if (s->steps_now > 1 && F.its > 0 && !(beta < F.beta_prev)) {
+      // a whole restart cycle without progress: the chained cycles are not helping on this right-hand side
+      msg (s, 1, "fgmres: no progress over a restart cycle with %d preconditioner cycles per iteration; continuing with one\n", s->steps_now);
+      s->steps_now = 1;
+   }
+   F.stalled_cycles = (F.cycle_ended_on_estimate && beta > 0.7 * F.beta_prev) ? F.stalled_cycles + 1 : 0;
+   if (F.stalled_cycles >= 3) { F.status = NKP_NOT_CONVERGED; s->stagnated = true; F.finished = true; return NKP_OK; }
+   if (F.cycle_ended_on_estimate && F.est_at_exit > 0.0) F.inner_scale = fmax (1e-3, fmin (F.inner_scale, 0.5 * F.est_at_exit / beta));
+   F.beta_prev = beta;
+   F.cycle_ended_on_estimate = false;
+   // v0 = r / beta; in the row-weighted iteration v0 = R r / ||R r|| and the inner target is the same relative
+   // reduction in that norm (the inner_scale logic above corrects it from what the next true residual shows)
+   F.beta_it = beta;
+   F.target_it = F.target;
+   if (s->equil) {
+      launch_vmul (s->r, s->rscale, s->r, n, st);
+      double q2 = 0.0;
+      if ((rc = dot_host (s, s->r, s->r, &q2))) return rc;
+      F.beta_it = sqrt (q2);
+      if (!(F.beta_it > 0.0)) { F.status = NKP_BREAKDOWN; F.finished = true; return NKP_OK; }
+      F.target_it = F.target * (F.beta_it / beta);
+   }
+   s->hpin[0] = 1.0 / F.beta_it;
+   HIPCHK (hipMemcpyAsync (s->misc_dev () + 1, s->hpin, sizeof (double), hipMemcpyHostToDevice, st));
+   if (s->vf32) launch_scale_to (s->r, s->misc_dev () + 1, s->vcur, (float *) s->V, n, st);
+   else launch_scale_to (s->r, s->misc_dev () + 1, s->V, nullptr, n, st);
+   HIPCHK (hipStreamSynchronize (st));      // hpin is reused below
+   F.g[0] = F.beta_it;
+   F.j = 0;
+   F.breakdown_in_cycle = false;
+   return NKP_OK;
+}
+
+// column j of the Hessenberg matrix is in s->hpin[0 .. j+1] (copied and synchronised by the caller): Givens rotations, the
+// residual estimate.  Returns true when this system's restart cycle ends here (estimate met, breakdown, column budget).
+static bool fg_post_step (nkp_solver *s, FgmresState &F)
+{
+   const int m = s->m, j = F.j;
+   double *hc = &F.H[(size_t) j * (m + 1)];
+   for (int i = 0; i <= j + 1; i++) hc[i] = s->hpin[i];
+   for (int i = 0; i < j; i++) {
+      const double t = F.cs[i] * hc[i] + F.sn[i] * hc[i + 1];
+      hc[i + 1] = -F.sn[i] * hc[i] + F.cs[i] * hc[i + 1];
+      hc[i] = t;
+   }
+   const double hjj = hc[j], hj1 = hc[j + 1];
+   const double d = hypot (hjj, hj1);
+   if (!(d > 0.0) || !(d == d)) { F.status = NKP_BREAKDOWN; F.breakdown_in_cycle = true; return true; }     // column j is unusable: keep k = j
+   F.cs[j] = hjj / d;
+   F.sn[j] = hj1 / d;
+   hc[j] = d;
+   hc[j + 1] = 0.0;
+   F.g[j + 1] = -F.sn[j] * F.g[j];
+   F.g[j] = F.cs[j] * F.g[j];
+   F.its++;
+   const double est = fabs (F.g[j + 1]);
+   msg (s, 3, "fgmres: its = %d, est relres = %.3e\n", F.its, est / F.bnorm);
+   F.j = j + 1;
+   if (est <= F.target_it * F.inner_scale || hj1 == 0.0) {
+      F.cycle_ended_on_estimate = true;
+      F.est_at_exit = est * (F.beta / F.beta_it);
+      return true;
+   }
+   return F.j >= m || F.its >= s->opt.max_iters;
+}
+
+// y = H^-1 g (upper triangular, size F.j), x += Z y; after a breakdown the true residual of what we have decides
+static int fg_end_cycle (nkp_solver *s, FgmresState &F)
+{
+   const int m = s->m, k = F.j;
+   hipStream_t st = s->stream;
+   for (int i = k - 1; i >= 0; i--) {
+      double t = F.g[i];
+      for (int c = i + 1; c < k; c++) t -= F.H[(size_t) c * (m + 1) + i] * F.y[c];
+      F.y[i] = t / F.H[(size_t) i * (m + 1) + i];
+   }
+   for (int i = 0; i < k; i++) s->hpin[i] = F.y[i];
+   HIPCHK (hipMemcpyAsync (s->y_dev (), s->hpin, (size_t) k * sizeof (double), hipMemcpyHostToDevice, st));
+   launch_axpy_multi (s->Z, s->ld, k, s->y_dev (), s->x, s->n, st);
+   HIPCHK (hipStreamSynchronize (st));
+   if (F.breakdown_in_cycle) {
+      // report the true residual of what we have
+      int rc;
       double r2 = 0.0;
+      spmv_op (s, s->x, s->r, s->b, 1);
       if ((rc = dot_host (s, s->r, s->r, &r2))) return rc;
-      const double beta = sqrt (r2);
-      relres = beta / bnorm;
-      msg (s, 2, "fgmres: its = %d, true relres = %.3e\n", its, relres);
-      if (s->comm_failed) return fail (NKP_ECOMM, "nkp_solve: a collective of the distributed solve failed");
-      if (!(beta == beta)) { status = NKP_BREAKDOWN; break; }
-      if (beta <= target) { status = NKP_OK; break; }
-      if (its >= s->opt.max_iters) { status = NKP_NOT_CONVERGED; break; }
-      if (s->steps_now > 1 && its > 0 && !(beta < beta_prev)) {
-         // a whole restart cycle without progress: the chained cycles are not helping on this right-hand side
-         msg (s, 1, "fgmres: no progress over a restart cycle with %d preconditioner cycles per iteration; continuing with one\n", s->steps_now);
-         s->steps_now = 1;
+      F.relres = sqrt (r2) / F.bnorm;
+      F.status = sqrt (r2) <= F.target ? NKP_OK : NKP_BREAKDOWN;
+      F.finished = true;
+   }
+   return NKP_OK;
+}
+
+static int fgmres (nkp_solver *s, int *iters_out, double *relres_out)
+{
+   FgmresState F;
+   int rc = fg_begin (s, F);
+   if (rc) return rc;
+   while (!F.finished) {
+      if ((rc = fg_restart (s, F))) return rc;
+      if (F.finished) break;
+      for (;;) {
+         arnoldi_step_device (s, F.j);
+         HIPCHK (hipMemcpyAsync (s->hpin, s->h_dev (), (size_t) (F.j + 2) * sizeof (double), hipMemcpyDeviceToHost, s->stream));
+         HIPCHK (hipStreamSynchronize (s->stream));
+         if (s->comm_failed) return fail (NKP_ECOMM, "nkp_solve: a collective of the distributed solve failed (Arnoldi step %d)", F.its + 1);
+         if (fg_post_step (s, F)) break;
       }
-      stalled_cycles = (cycle_ended_on_estimate && beta > 0.7 * beta_prev) ? stalled_cycles + 1 : 0;
-      if (stalled_cycles >= 3) { status = NKP_NOT_CONVERGED; s->stagnated = true; break; }
-      if (cycle_ended_on_estimate && est_at_exit > 0.0) inner_scale = fmax (1e-3, fmin (inner_scale, 0.5 * est_at_exit / beta));
-      beta_prev = beta;
-      cycle_ended_on_estimate = false;
-      // v0 = r / beta; in the row-weighted iteration v0 = R r / ||R r|| and the inner target is the same relative
-      // reduction in that norm (the inner_scale logic above corrects it from what the next true residual shows)
-      double beta_it = beta, target_it = target;
-      if (s->equil) {
-         launch_vmul (s->r, s->rscale, s->r, n, st);
-         double q2 = 0.0;
-         if ((rc = dot_host (s, s->r, s->r, &q2))) return rc;
-         beta_it = sqrt (q2);
-         if (!(beta_it > 0.0)) { status = NKP_BREAKDOWN; break; }
-         target_it = target * (beta_it / beta);
-      }
-      s->hpin[0] = 1.0 / beta_it;
-      HIPCHK (hipMemcpyAsync (s->misc_dev () + 1, s->hpin, sizeof (double), hipMemcpyHostToDevice, st));
-      if (s->vf32) launch_scale_to (s->r, s->misc_dev () + 1, s->vcur, (float *) s->V, n, st);
-      else launch_scale_to (s->r, s->misc_dev () + 1, s->V, nullptr, n, st);
-      HIPCHK (hipStreamSynchronize (st));      // hpin is reused below
-      g[0] = beta_it;
-      int j = 0;
-      for (; j < m && its < s->opt.max_iters; j++) {
-         arnoldi_step_device (s, j);
-         HIPCHK (hipMemcpyAsync (s->hpin, s->h_dev (), (size_t) (j + 2) * sizeof (double), hipMemcpyDeviceToHost, st));
-         HIPCHK (hipStreamSynchronize (st));
-         if (s->comm_failed) return fail (NKP_ECOMM, "nkp_solve: a collective of the distributed solve failed (Arnoldi step %d)", its + 1);
-         double *hc = &H[(size_t) j * (m + 1)];
-         for (int i = 0; i <= j + 1; i++) hc[i] = s->hpin[i];
-         for (int i = 0; i < j; i++) {
-            const double t = cs[i] * hc[i] + sn[i] * hc[i + 1];
-            hc[i + 1] = -sn[i] * hc[i] + cs[i] * hc[i + 1];
-            hc[i] = t;
-         }
-         const double hjj = hc[j], hj1 = hc[j + 1];
-         const double d = hypot (hjj, hj1);
-         if (!(d > 0.0) || !(d == d)) { status = NKP_BREAKDOWN; break; }     // column j is unusable: keep k = j
-         cs[j] = hjj / d;
-         sn[j] = hj1 / d;
-         hc[j] = d;
-         hc[j + 1] = 0.0;
-         g[j + 1] = -sn[j] * g[j];
-         g[j] = cs[j] * g[j];
-         its++;
-         const double est = fabs (g[j + 1]);
-         msg (s, 3, "fgmres: its = %d, est relres = %.3e\n", its, est / bnorm);
-         if (est <= target_it * inner_scale || hj1 == 0.0) { j++; cycle_ended_on_estimate = true; est_at_exit = est * (beta / beta_it); break; }
-      }
-      // y = H^-1 g (upper triangular, size j), x += Z y
-      const int k = j;
-      for (int i = k - 1; i >= 0; i--) {
-         double t = g[i];
-         for (int c = i + 1; c < k; c++) t -= H[(size_t) c * (m + 1) + i] * y[c];
-         y[i] = t / H[(size_t) i * (m + 1) + i];
-      }
-      for (int i = 0; i < k; i++) s->hpin[i] = y[i];
-      HIPCHK (hipMemcpyAsync (s->y_dev (), s->hpin, (size_t) k * sizeof (double), hipMemcpyHostToDevice, st));
-      launch_axpy_multi (s->Z, ld, k, s->y_dev (), s->x, n, st);
-      HIPCHK (hipStreamSynchronize (st));
-      if (status == NKP_BREAKDOWN) {
-         // report the true residual of what we have
-         spmv_op (s, s->x, s->r, s->b, 1);
-         if ((rc = dot_host (s, s->r, s->r, &r2))) return rc;
-         relres = sqrt (r2) / bnorm;
-         if (sqrt (r2) <= target) status = NKP_OK;
-         break;
-      }
+      if ((rc = fg_end_cycle (s, F))) return rc;
    }
    HIPCHK (hipGetLastError ());
-   *iters_out = its;
-   *relres_out = relres;
-   return status;
+   *iters_out = F.its;
+   *relres_out = F.relres;
+   return F.status;
 }
 
 // right-preconditioned BiCGStab; every inner product is a deterministic two-stage reduction
@@ -1052,6 +1130,9 @@ extern "C" int nkp_clone (nkp_solver *src, nkp_solver **out)
    if (!s) return fail (NKP_ENOMEM, "nkp_clone: out of host memory");
    s->borrowed = true;
    s->stagnated = false;
+   s->batch_members.clear ();
+   s->bvin = s->bz = s->bw = nullptr;
+   s->batch_K = 0;
    s->A.tune = &s->tune;
    s->B.tune = &s->tune;
    s->ml.tune = &s->tune;
@@ -1103,6 +1184,172 @@ extern "C" int nkp_clone (nkp_solver *src, nkp_solver **out)
    return NKP_OK;
 }
 
+// ---------------------------------------------------------------- K right-hand sides in lockstep
+// The reference's RHS loop (src/solve_ABglobal.c:370-409) as ONE pass over the matrix and the hierarchy per Krylov step for K
+// systems: every system keeps its own FGMRES recurrence (own basis, own Hessenberg matrix, own restart decisions -- the state
+// machine above), but the K applications of the cycle and of A in a step are one application to K interleaved vectors
+// (batch.hip).  Per system the operations and their order are those of a solve done alone, so are the bits.
+static const char *batch_unsupported (const nkp_solver *s)
+{
+   if (s->dist.on) return "the row-distributed flavour";
+   if (s->borrowed) return "a clone";
+   if (s->opt.krylov != NKP_KRYLOV_FGMRES) return "BiCGStab";
+   if (s->equil) return "row equilibration";
+   if (s->precond_steps > 1) return "chained preconditioner cycles";
+   if (s->vf32) return "an f32 Krylov basis";
+   return nullptr;
+}
+
+static int batch_prepare (nkp_solver *s, int K)
+{
+   while ((int) s->batch_members.size () < K - 1) {
+      nkp_solver *c = nullptr;
+      const int rc = nkp_clone (s, &c);
+      if (rc) return rc;
+      if (c->own_stream && c->stream) (void) hipStreamDestroy (c->stream);
+      c->stream = s->stream;
+      c->own_stream = false;
+      s->batch_members.push_back (c);
+   }
+   if (s->batch_K < K) {
+      for (double **p : { &s->bvin, &s->bz, &s->bw }) {
+         if (*p) { (void) hipFree (*p); *p = nullptr; }
+         const int rc = dev_alloc (s, p, (size_t) s->ld * (size_t) K);
+         if (rc) return rc;
+         HIPCHK (hipMemset (*p, 0, (size_t) s->ld * (size_t) K * sizeof (double)));
+      }
+      s->batch_K = K;
+   }
+   if (s->opt.precond == NKP_PRECOND_MULTILEVEL) {
+      const size_t before = s->ml.device_bytes;
+      const int mrc = ml_batch_prepare (s->ml, K);
+      if (mrc) return fail (NKP_ENOMEM, "nkp_solve_batch: device memory for the level vectors of %d right-hand sides", K);
+      s->device_bytes += s->ml.device_bytes - before;
+   }
+   return NKP_OK;
+}
+
+// z_k = M^-1 v_k, w_k = A z_k for the running systems; v, z, w per system, the application batched
+static void batch_apply (nkp_solver *s, int K, nkp_solver *const *mem, const bool *running, int j)
+{
+   const int64_t ld = s->ld, n = s->n;
+   hipStream_t st = s->stream;
+   const double *src[4] = { nullptr, nullptr, nullptr, nullptr };
+   double *dz[4] = { nullptr, nullptr, nullptr, nullptr }, *dw[4] = { nullptr, nullptr, nullptr, nullptr };
+   for (int k = 0; k < K; k++)
+      if (mem[k] && running[k]) { src[k] = mem[k]->V + (int64_t) j * ld; dz[k] = mem[k]->Z + (int64_t) j * ld; dw[k] = mem[k]->w; }
+   launch_interleave (K, src, s->bvin, n, st);
+   if (s->opt.precond == NKP_PRECOND_MULTILEVEL) ml_apply_batch (s->ml, K, s->bvin, s->bz, st);
+   else if (s->opt.precond == NKP_PRECOND_COLUMN_JACOBI) {
+      if (launch_colblock_apply_lanes_batch (K, s->B, 0, s->B.ngrp, s->bvin, s->bz, 0, st) != 0)
+         launch_colblock_apply_wave_batch (K, s->B, 0, s->B.nblk, s->bvin, s->bz, 0, s->B.fac_tf ? 1 : 0, st);
+   } else
+      launch_copy (s->bvin, s->bz, n * K, st);
+   launch_csr_spmv_batch (K, s->A, 0, s->A.nrowblk, s->bz, s->bw, nullptr, 0, st);
+   launch_deinterleave (K, s->bz, dz, n, st);
+   launch_deinterleave (K, s->bw, dw, n, st);
+}
+
+// mem[k]->b / ->x hold right-hand side and initial guess of system k (k < nact); on return ->x holds the solutions
+static int fgmres_batch (nkp_solver *s, int K, int nact, nkp_solver *const *mem, FgmresState *F)
+{
+   int rc;
+   for (int k = 0; k < nact; k++)
+      if ((rc = fg_begin (mem[k], F[k]))) return rc;
+   for (;;) {
+      bool running[4] = { false, false, false, false }, in_cycle[4] = { false, false, false, false };
+      int nrun = 0;
+      for (int k = 0; k < nact; k++) {
+         if (F[k].finished) continue;
+         if ((rc = fg_restart (mem[k], F[k]))) return rc;
+         running[k] = in_cycle[k] = !F[k].finished;
+         nrun += running[k] ? 1 : 0;
+      }
+      if (!nrun) break;
+      // the running systems advance together: all of them are at column j of their cycle
+      for (int j = 0; nrun; j++) {
+         batch_apply (s, K, mem, running, j);
+         for (int k = 0; k < nact; k++) {
+            if (!running[k]) continue;
+            arnoldi_orthogonalise (mem[k], j);
+            HIPCHK (hipMemcpyAsync (mem[k]->hpin, mem[k]->h_dev (), (size_t) (j + 2) * sizeof (double), hipMemcpyDeviceToHost, s->stream));
+         }
+         HIPCHK (hipStreamSynchronize (s->stream));
+         for (int k = 0; k < nact; k++)
+            if (running[k] && fg_post_step (mem[k], F[k])) { running[k] = false; nrun--; }      // this system's cycle is over; it waits for the others
+      }
+      for (int k = 0; k < nact; k++)
+         if (in_cycle[k] && (rc = fg_end_cycle (mem[k], F[k]))) return rc;
+   }
+   HIPCHK (hipGetLastError ());
+   return NKP_OK;
+}
+
+static int sev_of (int c) { return c == NKP_OK ? 0 : c == NKP_OK_BERR ? 1 : c == NKP_NOT_CONVERGED ? 2 : 3; }
+
+extern "C" int nkp_solve_batch_device (nkp_solver *s, int nrhs, const void *d_B, void *d_X, int64_t ldb, double *berr, int *iters, double *relres)
+{
+   if (!s || nrhs < 0 || (nrhs > 0 && (!d_B || !d_X))) return fail (NKP_EINVAL, "nkp_solve_batch_device: NULL argument");
+   if (nrhs > 0 && ldb < s->n) return fail (NKP_EINVAL, "nkp_solve_batch_device: ldb < n");
+   HIPCHK (hipSetDevice (s->device));
+   const double *B = (const double *) d_B;
+   double *X = (double *) d_X;
+   const size_t bytes = (size_t) s->n * sizeof (double);
+   int worst = NKP_OK;
+   const char *why = batch_unsupported (s);
+   if (why || nrhs < 2 || !s->tune.rhs_batch) {
+      // one at a time (the reference's loop); `why` names what the batched path does not cover
+      for (int c = 0; c < nrhs; c++) {
+         const int status = nkp_solve_device (s, B + (size_t) c * (size_t) ldb, X + (size_t) c * (size_t) ldb, 0, berr ? berr + c : nullptr, iters ? iters + c : nullptr, relres ? relres + c : nullptr);
+         if (status < 0) return status;
+         if (sev_of (status) > sev_of (worst)) worst = status;
+      }
+      return worst;
+   }
+   for (int c0 = 0; c0 < nrhs; c0 += 4) {
+      const int nact = nrhs - c0 < 4 ? nrhs - c0 : 4;
+      if (nact == 1) {
+         const int status = nkp_solve_device (s, B + (size_t) c0 * (size_t) ldb, X + (size_t) c0 * (size_t) ldb, 0, berr ? berr + c0 : nullptr, iters ? iters + c0 : nullptr, relres ? relres + c0 : nullptr);
+         if (status < 0) return status;
+         if (sev_of (status) > sev_of (worst)) worst = status;
+         break;
+      }
+      const int K = nact <= 2 ? 2 : 4;
+      int rc = batch_prepare (s, K);
+      if (rc) return rc;
+      nkp_solver *mem[4] = { s, nullptr, nullptr, nullptr };
+      for (int k = 1; k < K; k++) mem[k] = s->batch_members[(size_t) k - 1];
+      for (int k = 0; k < nact; k++) {
+         HIPCHK (hipMemsetAsync (mem[k]->x, 0, bytes, s->stream));
+         HIPCHK (hipMemcpyAsync (mem[k]->b, B + (size_t) (c0 + k) * (size_t) ldb, bytes, hipMemcpyDeviceToDevice, s->stream));
+         mem[k]->stagnated = false;
+      }
+      FgmresState F[4];
+      if ((rc = fgmres_batch (s, K, nact, mem, F)) < 0) return rc;
+      for (int k = 0; k < nact; k++) {
+         // the verdict of one system, exactly as solve_resident gives it for a solve done alone
+         nkp_solver *q = mem[k];
+         int status = F[k].status;
+         double be = 0.0;
+         if (berr || q->stagnated) {
+            if ((rc = backward_error (q, &be))) return rc;
+            if (berr) berr[c0 + k] = be;
+         }
+         if (status == NKP_NOT_CONVERGED && q->stagnated && be <= fmax (NKP_BERR_ROUNDING_LEVEL, 1.0e-2 * s->opt.rtol)) status = NKP_OK_BERR;
+         if (iters) iters[c0 + k] = F[k].its;
+         if (relres) relres[c0 + k] = F[k].relres;
+         msg (s, 1, "nkp_solve_batch: right-hand side %d: %s after %d iterations, ||b-Ax||/||b|| = %.3e\n", c0 + k,
+              status == NKP_OK ? "converged" : status == NKP_OK_BERR ? "at the attainable accuracy (backward error accepted)" : status == NKP_BREAKDOWN ? "breakdown" : "NOT converged", F[k].its, F[k].relres);
+         if (status != NKP_OK) fail (status, "nkp_solve_batch: right-hand side %d: %s after %d iterations (relres %.3e, rtol %.1e)", c0 + k,
+                                     status == NKP_OK_BERR ? "stopped above rtol at the attainable accuracy" : status == NKP_BREAKDOWN ? "breakdown" : "not converged", F[k].its, F[k].relres, s->opt.rtol);
+         if (sev_of (status) > sev_of (worst)) worst = status;
+         HIPCHK (hipMemcpyAsync (X + (size_t) (c0 + k) * (size_t) ldb, q->x, bytes, hipMemcpyDeviceToDevice, s->stream));
+      }
+      HIPCHK (hipStreamSynchronize (s->stream));
+   }
+   return worst;
+}
+
 extern "C" int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t ldb, double *berr, int *iters, double *relres)
 {
    if (!s || (nrhs > 0 && !b_in_x_out)) return fail (NKP_EINVAL, "nkp_solve: NULL argument");
@@ -1110,6 +1357,21 @@ extern "C" int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t l
    HIPCHK (hipSetDevice (s->device));
    const size_t bytes = (size_t) s->n * sizeof (double);
    int worst = NKP_OK;
+   if (nrhs >= 2 && s->tune.rhs_batch && !batch_unsupported (s)) {
+      // several right-hand sides share the sweeps over the matrix and the hierarchy (same bits per column as one at a time)
+      double *dB = nullptr;
+      const int64_t ldd = s->ld;
+      if (hipMalloc ((void **) &dB, (size_t) ldd * (size_t) nrhs * sizeof (double)) != hipSuccess) return fail (NKP_ENOMEM, "nkp_solve: device memory for %d right-hand sides", nrhs);
+      int status = NKP_OK;
+      for (int c = 0; c < nrhs && status == NKP_OK; c++)
+         if (hipMemcpy (dB + (size_t) c * (size_t) ldd, b_in_x_out + (size_t) c * (size_t) ldb, bytes, hipMemcpyHostToDevice) != hipSuccess) status = fail (NKP_EDEVICE, "nkp_solve: upload of right-hand side %d failed", c);
+      if (status == NKP_OK) status = nkp_solve_batch_device (s, nrhs, dB, dB, ldd, berr, iters, relres);
+      if (status >= 0)
+         for (int c = 0; c < nrhs; c++)
+            if (hipMemcpy (b_in_x_out + (size_t) c * (size_t) ldb, dB + (size_t) c * (size_t) ldd, bytes, hipMemcpyDeviceToHost) != hipSuccess) status = fail (NKP_EDEVICE, "nkp_solve: download of solution %d failed", c);
+      (void) hipFree (dB);
+      return status;
+   }
    for (int c = 0; c < nrhs; c++) {          // nrhs = 0 is the reference's factor-only call: nothing to do
       double *col = b_in_x_out + (size_t) c * (size_t) ldb;
       HIPCHK (hipMemcpyAsync (s->b, col, bytes, hipMemcpyHostToDevice, s->stream));
@@ -1119,8 +1381,7 @@ extern "C" int nkp_solve (nkp_solver *s, double *b_in_x_out, int nrhs, int64_t l
       HIPCHK (hipMemcpyAsync (col, s->x, bytes, hipMemcpyDeviceToHost, s->stream));
       HIPCHK (hipStreamSynchronize (s->stream));
       // severity: OK < OK_BERR < NOT_CONVERGED < BREAKDOWN
-      auto sev = [] (int c) { return c == NKP_OK ? 0 : c == NKP_OK_BERR ? 1 : c == NKP_NOT_CONVERGED ? 2 : 3; };
-      if (sev (status) > sev (worst)) worst = status;
+      if (sev_of (status) > sev_of (worst)) worst = status;
    }
    return worst;
 }

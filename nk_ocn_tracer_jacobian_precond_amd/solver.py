@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "nkp_comm_rccl_init", "nkp_comm_rccl_free", "nkp_create_dist", "nkp_dist_plan_host", "nkp_set_device",
     "nkp_gather_root", "nkp_clone", "nkp_ml_plan_host", "nkp_comm_file_init", "nkp_comm_file_free",
     "nkp_create64", "nkp_cell_major_order", "nkp_permuted_rows", "nkp_dist_overlap_plan_host", "nkp_dist_plan_size",
-    "nkp_dist_plan_copy", "nkp_dist_plan_free", "nkp_ml_level_array", "nkp_default_tuning",
+    "nkp_dist_plan_copy", "nkp_dist_plan_free", "nkp_ml_level_array", "nkp_default_tuning", "nkp_solve_batch_device",
 ]
 
 _ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p)
@@ -54,7 +54,7 @@ class NkpTuning(C.Structure):
         ("col_ldsres", C.c_int), ("col_stream", C.c_int), ("col_stream_min", C.c_int), ("col_stream_gw", C.c_int), ("col_wave_max", C.c_int),
         ("col_w3", C.c_int), ("col_group", C.c_int), ("col_pipe_min", C.c_int), ("col_ldsres_early", C.c_int), ("col_ldsres_packed", C.c_int),
         ("spmv_variant", C.c_int), ("spmv_compress", C.c_int), ("spmv_pipe_min", C.c_int), ("spmv_run", C.c_int), ("spmv_wgs", C.c_int),
-        ("precond_steps", C.c_int), ("equil", C.c_int), ("dist_overlap", C.c_int), ("dist_ras", C.c_int), ("force_dist", C.c_int),
+        ("rhs_batch", C.c_int), ("precond_steps", C.c_int), ("equil", C.c_int), ("dist_overlap", C.c_int), ("dist_ras", C.c_int), ("force_dist", C.c_int),
         ("setup_threads", C.c_int), ("plan_times", C.c_int), ("ml_drop_intertracer", C.c_int),
     ]
 
@@ -97,6 +97,7 @@ def load_library(path=None):
     lib.nkp_create64.argtypes = [C.POINTER(vp), C.POINTER(NkpOptions), C.c_int64, C.POINTER(C.c_int64), i32p, f64p, i32p, C.c_int64, C.c_int]
     lib.nkp_solve.argtypes = [vp, f64p, C.c_int, C.c_int64, f64p, C.POINTER(C.c_int), f64p]
     lib.nkp_solve_device.argtypes = [vp, vp, vp, C.c_int, f64p, C.POINTER(C.c_int), f64p]
+    lib.nkp_solve_batch_device.argtypes = [vp, C.c_int, vp, vp, C.c_int64, f64p, C.POINTER(C.c_int), f64p]
     lib.nkp_spmv.argtypes = [vp, f64p, f64p]
     lib.nkp_spmv_device.argtypes = [vp, vp, vp]
     lib.nkp_precond_apply.argtypes = [vp, f64p, f64p]
@@ -303,6 +304,23 @@ class NkpSolver:
                                         C.byref(iters), C.byref(relres))
         self._check(rc, (0,) if raise_on_fail else (0, 1, 2, 3))
         return dict(status=rc, iters=iters.value, relres=relres.value, berr=berr.value)
+
+    def solve_batch_device(self, d_B, d_X, nrhs, ldb, raise_on_fail=True):
+        """nkp_solve_batch_device: nrhs right-hand sides resident on the device (vector c at d_B + 8 * c * ldb), solutions to d_X.
+        Returns one info dict per right-hand side."""
+        berr, relres, iters = (C.c_double * nrhs)(), (C.c_double * nrhs)(), (C.c_int * nrhs)()
+        rc = self._lib.nkp_solve_batch_device(self._h, nrhs, C.c_void_p(d_B), C.c_void_p(d_X), ldb, berr, iters, relres)
+        self._check(rc, (0,) if raise_on_fail else (0, 1, 2, 3))
+        return [dict(status=rc, iters=iters[c], relres=relres[c], berr=berr[c]) for c in range(nrhs)]
+
+    def solve_many(self, B, raise_on_fail=True):
+        """nkp_solve with nrhs = B.shape[0] host right-hand sides (rows of B); returns (X, infos)."""
+        X = np.array(B, np.float64, order="C", copy=True)
+        nrhs = X.shape[0]
+        berr, relres, iters = (C.c_double * nrhs)(), (C.c_double * nrhs)(), (C.c_int * nrhs)()
+        rc = self._lib.nkp_solve(self._h, _p(X, C.c_double), nrhs, X.shape[1], berr, iters, relres)
+        self._check(rc, (0,) if raise_on_fail else (0, 1, 2, 3))
+        return X, [dict(status=rc, iters=iters[c], relres=relres[c], berr=berr[c]) for c in range(nrhs)]
 
     def spmv(self, x):
         x = np.ascontiguousarray(x, np.float64)

@@ -1,0 +1,87 @@
+"""Several right-hand sides through one sweep of the matrix and the hierarchy (nkp_solve_batch_device / nkp_solve with nrhs > 1,
+csrc/batch.hip): the reference's RHS loop (src/solve_ABglobal.c:370-409) batched.  Every column must have the BITS of the solve
+done alone -- same iteration count, same residual, same solution -- for 2, 3, 4 and 5 right-hand sides (groups of four, a
+padded group, a single leftover), with every preconditioner, f32 and f64 storage of the hierarchy, long columns, coupled tracers."""
+import numpy as np
+import pytest
+
+import oracle_binding as ora
+from nk_ocn_tracer_jacobian_precond_amd import solver, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def medium():
+    """3 degree x 60 level problem of BASELINE.json configs[1] (upwind3 + isop)."""
+    p = synth.generate(imt=100, jmt=116, km=60, adv="upwind3", hmix="isop", seed=0)
+    return p, solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+
+
+def _case(name, medium):
+    cnt = 1
+    if name == "medium":
+        p, blk = medium
+    elif name == "long_columns":
+        p = synth.generate(imt=24, jmt=20, km=70, adv="centred", hmix="const", seed=5)
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    elif name == "tracers2":
+        p = synth.generate(imt=40, jmt=46, km=20, adv="upwind3", hmix="isop", coupled_tracer_cnt=2, seed=3)
+        cnt = 2
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, cnt)
+    else:
+        p = synth.generate(imt=24, jmt=20, km=12, adv="upwind3", hmix="isop", seed=0)
+        blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), cnt)
+    return p, blk, ci, cj, cnt
+
+
+@pytest.mark.parametrize("name,precond,f32", [("medium", solver.PRECOND_MULTILEVEL, "1"), ("medium", solver.PRECOND_MULTILEVEL, "0"),
+                                              ("long_columns", solver.PRECOND_MULTILEVEL, "1"), ("tracers2", solver.PRECOND_MULTILEVEL, "1"),
+                                              ("small", solver.PRECOND_COLUMN_JACOBI, "1"), ("small", solver.PRECOND_NONE, "1")])
+def test_batched_solves_have_the_bits_of_single_solves(name, precond, f32, medium, monkeypatch):
+    monkeypatch.setenv("NKP_ML_F32", f32)
+    p, blk, ci, cj, cnt = _case(name, medium)
+    rng = np.random.default_rng(11)
+    B = rng.standard_normal((5, p.flat_len))
+    B[2] *= 1e-3                                            # systems of a group converge at different steps
+    kw = dict(col_i=ci, col_j=cj) if precond == solver.PRECOND_MULTILEVEL else {}
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, coupled_tracer_cnt=cnt, precond=precond, rtol=1e-10, restart=60 if precond != solver.PRECOND_MULTILEVEL else 200,
+                          max_iters=4000, **kw) as s:
+        single = [s.solve(B[c], raise_on_fail=False) for c in range(5)]
+        for nrhs in (2, 3, 4, 5):
+            X, infos = s.solve_many(B[:nrhs], raise_on_fail=False)
+            for c in range(nrhs):
+                x1, i1 = single[c]
+                assert infos[c]["iters"] == i1["iters"] and infos[c]["relres"] == i1["relres"], (name, nrhs, c, infos[c], i1)
+                assert np.array_equal(X[c], x1), (name, nrhs, c, np.abs(X[c] - x1).max())
+        if precond != solver.PRECOND_NONE:
+            for c in range(5):
+                res = B[c] - ora.spmv(p.rowptr, p.colind, p.nzval, single[c][0])
+                assert np.linalg.norm(res) <= 1.0001e-10 * np.linalg.norm(B[c])
+
+
+def test_batch_falls_back_where_it_does_not_apply(medium, monkeypatch):
+    """BiCGStab, row equilibration and nkp_tuning.rhs_batch = 0 take the right-hand sides one at a time -- same answers."""
+    p, blk = medium
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    B = np.random.default_rng(12).standard_normal((2, p.flat_len))
+    for kw in (dict(tuning=dict(rhs_batch=0)), dict(equil=1)):
+        with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, rtol=1e-10, **kw) as s:
+            X, infos = s.solve_many(B)
+            for c in range(2):
+                x1, i1 = s.solve(B[c])
+                assert np.array_equal(X[c], x1) and infos[c]["iters"] == i1["iters"]
+
+
+def test_batch_zero_and_mixed_right_hand_sides(medium):
+    p, blk = medium
+    ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
+    B = np.random.default_rng(13).standard_normal((3, p.flat_len))
+    B[1] = 0.0
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, rtol=1e-10) as s:
+        X, infos = s.solve_many(B)
+        assert infos[1]["iters"] == 0 and not X[1].any()
+        for c in (0, 2):
+            x1, i1 = s.solve(B[c])
+            assert np.array_equal(X[c], x1) and infos[c]["iters"] == i1["iters"]
