@@ -90,7 +90,8 @@ typedef struct nkp_tuning {
    int ml_host_inverse;      /* NKP_ML_HOST_INVERSE (0): dense inverse of the last level on the host */
    int ml_fused;             /* NKP_ML_FUSED (0): one launch per Gauss-Seidel half sweep */
    int ml_fused_max_cols;    /* NKP_ML_FUSED_MAX_COLS (0 = all): ... only on levels with at most that many columns */
-   int ml_wave_fused;        /* NKP_ML_WAVE_FUSED (1): levels solved one column per wave run each half sweep as ONE launch */
+   int ml_wave_fused;        /* NKP_ML_WAVE_FUSED (1): levels solved one column per wave run each half sweep as ONE launch;
+                                0 = never, N > 1 = only levels with at most N columns */
    int ml_coarsest_sweeps;   /* NKP_ML_COARSEST_SWEEPS (30): sweeps on a last level too large for a dense inverse */
    int64_t ml_tail_rows;     /* NKP_ML_TAIL_ROWS (0): the last levels with at most that many rows in one launch */
    double ml_omega;          /* NKP_ML_OMEGA (1.1): weight of the coarse-grid correction */
@@ -122,6 +123,8 @@ typedef struct nkp_tuning {
    int setup_threads;        /* NKP_SETUP_THREADS (0 = automatic): host threads of the setup loops */
    int plan_times;           /* NKP_ML_PLAN_TIMES (0): print the split of the host-side aggregation */
    int ml_drop_intertracer;  /* NKP_ML_DROP_INTERTRACER (0): developer switch, hierarchy without inter-tracer couplings */
+   int batch_spmv_rows;      /* NKP_BATCH_SPMV_ROWS (1): batched SpMV stages the (value, column) stream in LDS and lets each row's lane gather
+                                its own K-wide rows of x; 0 = products parked in LDS, K / 2 passes */
 } nkp_tuning;
 
 /* defaults, then the NKP_* environment overrides listed above */

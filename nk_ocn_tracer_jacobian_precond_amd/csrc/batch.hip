@@ -145,18 +145,134 @@ void csr_spmv_batch_kernel (const int *__restrict__ rowblk_all, int rb0, int nro
    }
 }
 
+// The other way round: the workgroup stages the row block's (value, column) stream in LDS with coalesced loads (8 bytes per
+// entry instead of 16 K of products: 16 KB per workgroup, twice the workgroups per CU), then every row's lane walks its own
+// segment, gathers the K-wide rows of x itself (GU entries in flight) and accumulates its K sums in registers -- same
+// products, same stored order, one pass for any K.
+// SPLIT: the K results of a row go to K separate vectors (split.p[k][r]; NULL = dropped) instead of the interleaved y -- the
+// operator product at the end of an Arnoldi step writes every system's w directly.
+template <int MODE, class VT, int K, bool SPLIT = false>
+__global__ __launch_bounds__ (BT_THREADS)
+void csr_spmv_batch_rows_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk, int per_xcd, const int *__restrict__ rowptr,
+                                 const int *__restrict__ colind, const VT *__restrict__ val, const double *__restrict__ x,
+                                 double *__restrict__ y, const double *__restrict__ b, BatchOutPtrs split = BatchOutPtrs ())
+{
+   __shared__ VT sv[NKP_SPMV_LDS_NNZ];
+   __shared__ int sc[NKP_SPMV_LDS_NNZ];
+   __shared__ double2 wsum[BT_WAVES];
+   constexpr int SLOTS = NKP_SPMV_LDS_NNZ / BT_THREADS, GU = 16 / K;
+   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+   const int lb = xcd * per_xcd + idx;
+   if (idx >= per_xcd || lb >= nrowblk) return;
+   const int tid = threadIdx.x;
+   const int *rowblk = rowblk_all + rb0;
+   const int r0 = rowblk[lb], r1 = rowblk[lb + 1];
+   const int e0 = rowptr[r0], e1 = rowptr[r1];
+   const int cnt = e1 - e0;
+   if (cnt > NKP_SPMV_LDS_NNZ) {
+      for (int g = 0; g < K / 2; g++) {
+         double2 acc = make_double2 (0.0, 0.0);
+         for (int e = e0 + tid; e < e1; e += BT_THREADS) {
+            const double v = (double) val[e];
+            const double2 xv = *reinterpret_cast<const double2 *> (x + (int64_t) colind[e] * K + 2 * g);
+            acc.x += v * xv.x;
+            acc.y += v * xv.y;
+         }
+         for (int off = NKP_WAVE / 2; off > 0; off >>= 1) { acc.x += __shfl_down (acc.x, off); acc.y += __shfl_down (acc.y, off); }
+         if ((tid & (NKP_WAVE - 1)) == 0) wsum[tid / NKP_WAVE] = acc;
+         __syncthreads ();
+         if (tid == 0) {
+            double2 s = make_double2 (0.0, 0.0);
+            for (int w = 0; w < BT_WAVES; w++) { s.x += wsum[w].x; s.y += wsum[w].y; }
+            if (MODE == 1) { const double2 bv = *reinterpret_cast<const double2 *> (b + (int64_t) r0 * K + 2 * g); s.x = bv.x - s.x; s.y = bv.y - s.y; }
+            if (SPLIT) { if (split.p[2 * g]) split.p[2 * g][r0] = s.x; if (split.p[2 * g + 1]) split.p[2 * g + 1][r0] = s.y; }
+            else *reinterpret_cast<double2 *> (y + (int64_t) r0 * K + 2 * g) = s;
+         }
+         __syncthreads ();
+      }
+      return;
+   }
+   const int r = r0 + tid;
+   int s0 = 0, s1 = 0;
+   if (r < r1) { s0 = rowptr[r] - e0; s1 = rowptr[r + 1] - e0; }
+   {
+      VT v[SLOTS];
+      int c[SLOTS];
+#pragma unroll
+      for (int u = 0; u < SLOTS; u++) {
+         const int k = tid + u * BT_THREADS;
+         v[u] = k < cnt ? val[e0 + k] : (VT) 0;
+         c[u] = k < cnt ? colind[e0 + k] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < SLOTS; u++) {
+         const int k = tid + u * BT_THREADS;
+         if (k < cnt) { sv[k] = v[u]; sc[k] = c[u]; }
+      }
+   }
+   double2 bv[K / 2];
+#pragma unroll
+   for (int g = 0; g < K / 2; g++) bv[g] = (MODE == 1 && r < r1) ? *reinterpret_cast<const double2 *> (b + (int64_t) r * K + 2 * g) : make_double2 (0.0, 0.0);
+   __syncthreads ();
+   if (r >= r1) return;
+   double2 acc[K / 2];
+#pragma unroll
+   for (int g = 0; g < K / 2; g++) acc[g] = make_double2 (0.0, 0.0);
+   for (int k = s0; k < s1; k += GU) {
+      double vv[GU];
+      double2 xg[GU][K / 2];
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+         const int kk = k + u < s1 ? k + u : s1 - 1;
+         vv[u] = (double) sv[kk];
+         const double *xr = x + (int64_t) sc[kk] * K;
+#pragma unroll
+         for (int g = 0; g < K / 2; g++) xg[u][g] = *reinterpret_cast<const double2 *> (xr + 2 * g);
+      }
+#pragma unroll
+      for (int u = 0; u < GU; u++)
+         if (k + u < s1) {
+#pragma unroll
+            for (int g = 0; g < K / 2; g++) { acc[g].x += vv[u] * xg[u][g].x; acc[g].y += vv[u] * xg[u][g].y; }
+         }
+   }
+#pragma unroll
+   for (int g = 0; g < K / 2; g++) {
+      if (MODE == 1) { acc[g].x = bv[g].x - acc[g].x; acc[g].y = bv[g].y - acc[g].y; }
+      if (SPLIT) { if (split.p[2 * g]) split.p[2 * g][r] = acc[g].x; if (split.p[2 * g + 1]) split.p[2 * g + 1][r] = acc[g].y; }
+      else *reinterpret_cast<double2 *> (y + (int64_t) r * K + 2 * g) = acc[g];
+   }
+}
+
 void launch_csr_spmv_batch (int K, const CsrDev &A, int rb0, int rb1, const double *x, double *y, const double *b, int mode, hipStream_t st)
 {
    const int cnt = rb1 - rb0;
    if (cnt <= 0) return;
    const int per_xcd = (cnt + 7) / 8;
-#define BSPMV(MODE_, VT_, K_, VAL_) hipLaunchKernelGGL ((csr_spmv_batch_kernel<MODE_, VT_, K_>), dim3 (per_xcd * 8), dim3 (BT_THREADS), 0, st, \
-                                                        A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, VAL_, x, y, b)
-#define BSPMV_K(MODE_, VT_, VAL_) do { if (K == 2) BSPMV (MODE_, VT_, 2, VAL_); else BSPMV (MODE_, VT_, 4, VAL_); } while (0)
+   const nkp_tuning &T = A.tune ? *A.tune : nkp_builtin_tuning ();
+#define BSPMV(KERNEL_, MODE_, VT_, K_, VAL_) hipLaunchKernelGGL ((KERNEL_<MODE_, VT_, K_>), dim3 (per_xcd * 8), dim3 (BT_THREADS), 0, st, \
+                                                                 A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, VAL_, x, y, b)
+#define BSPMV_K(MODE_, VT_, VAL_) do { if (T.batch_spmv_rows) { if (K == 2) BSPMV (csr_spmv_batch_rows_kernel, MODE_, VT_, 2, VAL_); else BSPMV (csr_spmv_batch_rows_kernel, MODE_, VT_, 4, VAL_); } \
+                                       else { if (K == 2) BSPMV (csr_spmv_batch_kernel, MODE_, VT_, 2, VAL_); else BSPMV (csr_spmv_batch_kernel, MODE_, VT_, 4, VAL_); } } while (0)
    if (A.valf) { if (mode == 0) BSPMV_K (0, float, A.valf); else BSPMV_K (1, float, A.valf); }
    else { if (mode == 0) BSPMV_K (0, double, A.val); else BSPMV_K (1, double, A.val); }
 #undef BSPMV_K
 #undef BSPMV
+}
+
+// y_k = A x_k for the K interleaved columns of x, every result in its own vector (dst[k] NULL: not wanted)
+void launch_csr_spmv_batch_split (int K, const CsrDev &A, const double *x, double *const *dst, hipStream_t st)
+{
+   const int cnt = A.nrowblk;
+   if (cnt <= 0) return;
+   const int per_xcd = (cnt + 7) / 8;
+   BatchOutPtrs P;
+   for (int k = 0; k < 4; k++) P.p[k] = k < K ? dst[k] : nullptr;
+#define BSPLIT(VT_, K_, VAL_) hipLaunchKernelGGL ((csr_spmv_batch_rows_kernel<0, VT_, K_, true>), dim3 (per_xcd * 8), dim3 (BT_THREADS), 0, st, \
+                                                  A.rowblk, 0, cnt, per_xcd, A.rowptr, A.colind, VAL_, x, (double *) nullptr, (const double *) nullptr, P)
+   if (A.valf) { if (K == 2) BSPLIT (float, 2, A.valf); else BSPLIT (float, 4, A.valf); }
+   else { if (K == 2) BSPLIT (double, 2, A.val); else BSPLIT (double, 4, A.val); }
+#undef BSPLIT
 }
 
 // ---------------------------------------------------------------- grid transfer / permutation / coarsest solve, K columns
@@ -193,6 +309,36 @@ void gather_batch_kernel (const int *__restrict__ perm, const double *__restrict
       const int k = (int) (t % K);
       if (scatter) out[(int64_t) perm[i] * K + k] = in[t];
       else out[t] = in[(int64_t) perm[i] * K + k];
+   }
+}
+
+// the entry and the exit of a batched cycle application, fused with the (de-)interleave of the per-system vectors:
+//   entry: out[i * K + k] = src_k[perm[i]]        exit: z[perm[i] * K + k] = dst_k[perm[i]] = in[i * K + k]
+template <int K>
+__global__ __launch_bounds__ (BT_THREADS)
+void gather_interleave_kernel (const int *__restrict__ perm, BatchPtrs src, double *__restrict__ out, int64_t n)
+{
+   const int64_t stride = (int64_t) gridDim.x * BT_THREADS;
+   for (int64_t i = (int64_t) blockIdx.x * BT_THREADS + threadIdx.x; i < n; i += stride) {
+      const int64_t pi = perm[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) out[i * K + k] = src.p[k] ? src.p[k][pi] : 0.0;
+   }
+}
+
+template <int K>
+__global__ __launch_bounds__ (BT_THREADS)
+void scatter_split_kernel (const int *__restrict__ perm, const double *__restrict__ in, double *__restrict__ z, BatchOutPtrs dst, int64_t n)
+{
+   const int64_t stride = (int64_t) gridDim.x * BT_THREADS;
+   for (int64_t i = (int64_t) blockIdx.x * BT_THREADS + threadIdx.x; i < n; i += stride) {
+      const int64_t pi = perm[i];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+         const double v = in[i * K + k];
+         z[pi * K + k] = v;
+         if (dst.p[k]) dst.p[k][pi] = v;
+      }
    }
 }
 
@@ -239,6 +385,18 @@ void launch_gather_batch (int K, const int *perm, const double *in, double *out,
 void launch_scatter_batch (int K, const int *perm, const double *in, double *out, int64_t n, hipStream_t st)
 {
    if (n > 0) BT_K (gather_batch_kernel, dim3 (bt_grid (n * K)), perm, in, out, n, 1);
+}
+void launch_gather_interleave (int K, const int *perm, const double *const *src, double *out, int64_t n, hipStream_t st)
+{
+   BatchPtrs P;
+   for (int k = 0; k < 4; k++) P.p[k] = k < K ? src[k] : nullptr;
+   if (n > 0) BT_K (gather_interleave_kernel, dim3 (bt_grid (n)), perm, P, out, n);
+}
+void launch_scatter_split (int K, const int *perm, const double *in, double *z, double *const *dst, int64_t n, hipStream_t st)
+{
+   BatchOutPtrs P;
+   for (int k = 0; k < 4; k++) P.p[k] = k < K ? dst[k] : nullptr;
+   if (n > 0) BT_K (scatter_split_kernel, dim3 (bt_grid (n)), perm, in, z, P, n);
 }
 void launch_dense_matvec_batch (int K, const double *Minv, const double *x, double *y, int n, hipStream_t st)
 {

@@ -62,6 +62,7 @@ void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st);
 // column gets the bits ml_apply gives it alone.  ml_batch_prepare allocates the level vectors (0, or -2 = out of device memory).
 int ml_batch_prepare (MlHierarchy &H, int K);
 void ml_apply_batch (MlHierarchy &H, int K, const double *r, double *z, hipStream_t st);
+void ml_apply_batch_split (MlHierarchy &H, int K, const double *const *src, double *z, double *const *dst, hipStream_t st);
 // measurement helpers: launch one piece of a level-0 half sweep (0 residual rows, 1 column solves); compulsory HBM bytes of
 // that piece or of the whole cycle (2)
 void ml_time_piece (MlHierarchy &H, int which, hipStream_t st);

@@ -1013,7 +1013,7 @@ int finish_level_columns (MlHierarchy &H, MlLevel &V, int l, const std::vector<i
       if (lrc != 0) ML_FAIL (-3, "multilevel setup: lane layout of level %d failed (HIP error %d)", l, lrc);
       V.wave_columns = ncol <= H.tune->col_wave_max && V.B.dropped == 0;
       // ... and their half sweeps are one launch each (residual of the column's rows + its band solve, gs_wave_kernel)
-      V.wave_fused = V.wave_columns && H.tune->ml_wave_fused != 0;
+      V.wave_fused = V.wave_columns && (H.tune->ml_wave_fused == 1 || (H.tune->ml_wave_fused > 1 && ncol <= H.tune->ml_wave_fused));
       // the block-per-group fused kernel serves matching storage only (f32 operator with f32 factors, or f64 with f64)
       if (V.B.gs_ok && !((V.B.fac_tf && V.L.valf) || (V.B.fac_t && !V.L.valf))) V.B.gs_ok = 0;
       T.lay += secs_since (t_lay0);
@@ -1665,6 +1665,16 @@ void ml_apply_batch (MlHierarchy &H, int K, const double *r, double *z, hipStrea
    launch_gather_batch (K, H.perm0, r, V.bb, V.n, st);
    ml_cycle_batch (H, K, 0, st);
    launch_scatter_batch (K, H.perm0, V.bxnow (), z, V.n, st);
+}
+
+// the same from / to per-system vectors: src[k] = residual of system k (NULL: zeros), z = the K corrections interleaved,
+// dst[k] (may be NULL) = a plain copy of column k
+void ml_apply_batch_split (MlHierarchy &H, int K, const double *const *src, double *z, double *const *dst, hipStream_t st)
+{
+   MlLevel &V = H.lev[0];
+   launch_gather_interleave (K, H.perm0, src, V.bb, V.n, st);
+   ml_cycle_batch (H, K, 0, st);
+   launch_scatter_split (K, H.perm0, V.bxnow (), z, dst, V.n, st);
 }
 
 // ================================================================ measurement helpers (bench.py, probes)

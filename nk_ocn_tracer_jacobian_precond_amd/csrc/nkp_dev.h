@@ -167,6 +167,9 @@ void launch_restrict_sum_batch (int K, const int *rptr, const int *ridx, const d
 void launch_prolong_add_batch (int K, const int *cmap, const double *coarse, double *fine, int64_t nf, double omega, hipStream_t st);
 void launch_gather_batch (int K, const int *perm, const double *in, double *out, int64_t n, hipStream_t st);
 void launch_scatter_batch (int K, const int *perm, const double *in, double *out, int64_t n, hipStream_t st);
+void launch_gather_interleave (int K, const int *perm, const double *const *src, double *out, int64_t n, hipStream_t st);
+void launch_scatter_split (int K, const int *perm, const double *in, double *z, double *const *dst, int64_t n, hipStream_t st);
+void launch_csr_spmv_batch_split (int K, const CsrDev &A, const double *x, double *const *dst, hipStream_t st);
 void launch_dense_matvec_batch (int K, const double *Minv, const double *x, double *y, int n, hipStream_t st);
 // water-column solves of blocks [b0, b1), one column per wave / the fused half sweep, K columns
 void launch_colblock_apply_wave_batch (int K, const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, int r32, hipStream_t st);

@@ -86,7 +86,7 @@ static void builtin_tuning (nkp_tuning *t)
    t->col_ldsres = 2; t->col_stream = 1; t->col_stream_min = -1; t->col_stream_gw = 32; t->col_wave_max = 8192; t->col_w3 = 1;
    t->col_group = 8; t->col_pipe_min = 0; t->col_ldsres_early = 0; t->col_ldsres_packed = 1;
    t->spmv_variant = 4; t->spmv_compress = 0; t->spmv_pipe_min = 1024; t->spmv_run = 1; t->spmv_wgs = 256;
-   t->rhs_batch = 1; t->precond_steps = 0; t->equil = -1; t->dist_overlap = 1; t->dist_ras = 1; t->force_dist = 0; t->setup_threads = 0; t->plan_times = 0;
+   t->rhs_batch = 1; t->batch_spmv_rows = 1; t->precond_steps = 0; t->equil = -1; t->dist_overlap = 1; t->dist_ras = 1; t->force_dist = 0; t->setup_threads = 0; t->plan_times = 0;
    t->ml_drop_intertracer = 0;
 }
 
@@ -112,7 +112,7 @@ extern "C" int nkp_default_tuning (nkp_tuning *t)
    ENV_POS ("NKP_ML_SMOOTH_COARSE", ml_smooth_coarse); ENV_POS ("NKP_ML_COARSE_FROM", ml_coarse_from);
    ENV_INT ("NKP_ML_GAMMA_FROM", ml_gamma_from); ENV_INT ("NKP_ML_GAMMA_TO", ml_gamma_to);
    ENV_FLAG ("NKP_ML_F32", ml_f32); ENV_FLAG ("NKP_ML_HOST_INVERSE", ml_host_inverse); ENV_FLAG ("NKP_ML_FUSED", ml_fused);
-   ENV_INT ("NKP_ML_FUSED_MAX_COLS", ml_fused_max_cols); ENV_FLAG ("NKP_ML_WAVE_FUSED", ml_wave_fused); ENV_POS ("NKP_ML_COARSEST_SWEEPS", ml_coarsest_sweeps);
+   ENV_INT ("NKP_ML_FUSED_MAX_COLS", ml_fused_max_cols); ENV_INT ("NKP_ML_WAVE_FUSED", ml_wave_fused); ENV_POS ("NKP_ML_COARSEST_SWEEPS", ml_coarsest_sweeps);
    if ((e = getenv ("NKP_ML_TAIL_ROWS")) && *e) t->ml_tail_rows = atoll (e);
    if ((e = getenv ("NKP_ML_OMEGA")) && atof (e) > 0.0) t->ml_omega = atof (e);
    ENV_INT ("NKP_COL_LDSRES", col_ldsres); ENV_FLAG ("NKP_COLSTREAM", col_stream); ENV_INT ("NKP_COLSTREAM_MIN", col_stream_min);
@@ -121,7 +121,7 @@ extern "C" int nkp_default_tuning (nkp_tuning *t)
    ENV_INT ("NKP_COLPIPE_MIN", col_pipe_min); ENV_FLAG ("NKP_LDSRES_EARLY", col_ldsres_early); ENV_FLAG ("NKP_COL_PACKED", col_ldsres_packed);
    ENV_INT ("NKP_SPMV_VARIANT", spmv_variant); ENV_FLAG ("NKP_SPMV_COMPRESS", spmv_compress); ENV_INT ("NKP_SPMV_PIPE_MIN", spmv_pipe_min);
    ENV_POS ("NKP_SPMV_RUN", spmv_run); ENV_POS ("NKP_SPMV_WGS", spmv_wgs);
-   ENV_FLAG ("NKP_RHS_BATCH", rhs_batch);
+   ENV_FLAG ("NKP_RHS_BATCH", rhs_batch); ENV_FLAG ("NKP_BATCH_SPMV_ROWS", batch_spmv_rows);
    ENV_POS ("NKP_PRECOND_STEPS", precond_steps); ENV_FLAG ("NKP_EQUIL", equil);
    ENV_FLAG ("NKP_DIST_OVERLAP", dist_overlap); ENV_FLAG ("NKP_DIST_RAS", dist_ras);
    if (getenv ("NKP_FORCE_DIST")) t->force_dist = 1;
@@ -1238,16 +1238,23 @@ static void batch_apply (nkp_solver *s, int K, nkp_solver *const *mem, const boo
    double *dz[4] = { nullptr, nullptr, nullptr, nullptr }, *dw[4] = { nullptr, nullptr, nullptr, nullptr };
    for (int k = 0; k < K; k++)
       if (mem[k] && running[k]) { src[k] = mem[k]->V + (int64_t) j * ld; dz[k] = mem[k]->Z + (int64_t) j * ld; dw[k] = mem[k]->w; }
-   launch_interleave (K, src, s->bvin, n, st);
-   if (s->opt.precond == NKP_PRECOND_MULTILEVEL) ml_apply_batch (s->ml, K, s->bvin, s->bz, st);
-   else if (s->opt.precond == NKP_PRECOND_COLUMN_JACOBI) {
-      if (launch_colblock_apply_lanes_batch (K, s->B, 0, s->B.ngrp, s->bvin, s->bz, 0, st) != 0)
-         launch_colblock_apply_wave_batch (K, s->B, 0, s->B.nblk, s->bvin, s->bz, 0, s->B.fac_tf ? 1 : 0, st);
-   } else
-      launch_copy (s->bvin, s->bz, n * K, st);
-   launch_csr_spmv_batch (K, s->A, 0, s->A.nrowblk, s->bz, s->bw, nullptr, 0, st);
-   launch_deinterleave (K, s->bz, dz, n, st);
-   launch_deinterleave (K, s->bw, dw, n, st);
+   if (s->opt.precond == NKP_PRECOND_MULTILEVEL) {
+      // permutation into the hierarchy's row order and the (de-)interleave in one kernel each
+      ml_apply_batch_split (s->ml, K, src, s->bz, dz, st);
+   } else {
+      launch_interleave (K, src, s->bvin, n, st);
+      if (s->opt.precond == NKP_PRECOND_COLUMN_JACOBI) {
+         if (launch_colblock_apply_lanes_batch (K, s->B, 0, s->B.ngrp, s->bvin, s->bz, 0, st) != 0)
+            launch_colblock_apply_wave_batch (K, s->B, 0, s->B.nblk, s->bvin, s->bz, 0, s->B.fac_tf ? 1 : 0, st);
+      } else
+         launch_copy (s->bvin, s->bz, n * K, st);
+      launch_deinterleave (K, s->bz, dz, n, st);
+   }
+   if (s->tune.batch_spmv_rows) launch_csr_spmv_batch_split (K, s->A, s->bz, dw, st);
+   else {
+      launch_csr_spmv_batch (K, s->A, 0, s->A.nrowblk, s->bz, s->bw, nullptr, 0, st);
+      launch_deinterleave (K, s->bw, dw, n, st);
+   }
 }
 
 // mem[k]->b / ->x hold right-hand side and initial guess of system k (k < nact); on return ->x holds the solutions

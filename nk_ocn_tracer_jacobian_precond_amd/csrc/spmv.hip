@@ -315,6 +315,91 @@ void csr_spmv_pipe_kernel (const int *__restrict__ rowblk_all, int rb0, int nrow
 #undef SPMV_LOAD_CURRENT
 }
 
+// ---------------------------------------------------------------- rows variant (spmv_variant 9)
+// Found on the batched kernel (batch.hip) and brought back here: stage the block's (value, column) stream in LDS instead of
+// the products -- 8 bytes per entry for an f32 operator -- and let every row's lane walk its own segment, gathering x itself
+// with GU loads in flight and summing in registers.  No second pass over LDS with 8-byte products, half the LDS per
+// workgroup, and the gathers of a wave go to few neighbouring lines (lanes = consecutive rows of a column: their stencil
+// neighbours are consecutive too).  Same products, same stored order => same bits.
+template <int MODE, class VT>
+__global__ __launch_bounds__ (SPMV_THREADS)
+void csr_spmv_rows_kernel (const int *__restrict__ rowblk_all, int rb0, int nrowblk, int per_xcd,
+                           const int *__restrict__ rowptr, const int *__restrict__ colind,
+                           const VT *__restrict__ val, const double *__restrict__ x,
+                           double *__restrict__ y, const double *__restrict__ b)
+{
+   __shared__ VT sv[SPMV_LDS_NNZ];
+   __shared__ int sc[SPMV_LDS_NNZ];
+   __shared__ double wsum[SPMV_THREADS / NKP_WAVE];
+   constexpr int GU = 8;
+   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+   const int lb = xcd * per_xcd + idx;
+   if (idx >= per_xcd || lb >= nrowblk) return;
+   const int tid = threadIdx.x;
+   const int *rowblk = rowblk_all + rb0;
+   const int r0 = rowblk[lb], r1 = rowblk[lb + 1];
+   const int e0 = rowptr[r0], e1 = rowptr[r1];
+   const int cnt = e1 - e0;
+   if (cnt > SPMV_LDS_NNZ) {
+      double acc = 0.0;
+      for (int e = e0 + tid; e < e1; e += SPMV_THREADS) {
+         double p = (double) val[e] * x[colind[e]];
+         acc += (MODE == 2) ? fabs (p) : p;
+      }
+      for (int off = NKP_WAVE / 2; off > 0; off >>= 1) acc += __shfl_down (acc, off);
+      if ((tid & (NKP_WAVE - 1)) == 0) wsum[tid / NKP_WAVE] = acc;
+      __syncthreads ();
+      if (tid == 0) {
+         double s = 0.0;
+         for (int w = 0; w < SPMV_THREADS / NKP_WAVE; w++) s += wsum[w];
+         if (MODE == 1) s = b[r0] - s;
+         if (MODE == 2) s += fabs (b[r0]);
+         y[r0] = s;
+      }
+      return;
+   }
+   const int r = r0 + tid;
+   int s0 = 0, s1 = 0;
+   if (r < r1) { s0 = rowptr[r] - e0; s1 = rowptr[r + 1] - e0; }
+   {
+      VT v[SPMV_LDS_NNZ / SPMV_THREADS];
+      int c[SPMV_LDS_NNZ / SPMV_THREADS];
+#pragma unroll
+      for (int u = 0; u < SPMV_LDS_NNZ / SPMV_THREADS; u++) {
+         const int k = tid + u * SPMV_THREADS;
+         v[u] = k < cnt ? val[e0 + k] : (VT) 0;
+         c[u] = k < cnt ? colind[e0 + k] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < SPMV_LDS_NNZ / SPMV_THREADS; u++) {
+         const int k = tid + u * SPMV_THREADS;
+         if (k < cnt) { sv[k] = v[u]; sc[k] = c[u]; }
+      }
+   }
+   const double bv = (MODE != 0 && r < r1) ? b[r] : 0.0;
+   __syncthreads ();
+   if (r >= r1) return;
+   double acc = 0.0;
+   for (int k = s0; k < s1; k += GU) {
+      double vv[GU], xg[GU];
+#pragma unroll
+      for (int u = 0; u < GU; u++) {
+         const int kk = k + u < s1 ? k + u : s1 - 1;
+         vv[u] = (double) sv[kk];
+         xg[u] = x[sc[kk]];
+      }
+#pragma unroll
+      for (int u = 0; u < GU; u++)
+         if (k + u < s1) {
+            const double q = vv[u] * xg[u];
+            acc += (MODE == 2) ? fabs (q) : q;
+         }
+   }
+   if (MODE == 1) acc = bv - acc;
+   if (MODE == 2) acc += fabs (bv);
+   y[r] = acc;
+}
+
 void build_rowblocks_host (int64_t n, const int *rowptr, int **rowblk_out, int *nrowblk_out)
 {
    // worst case one block per row
@@ -356,6 +441,11 @@ static void launch_range (const CsrDev &A, int rb0, int cnt, const double *x, do
       if (A.valf) { if (A.codes) SPMV_PIPE (float, true, A.valf); else SPMV_PIPE (float, false, A.valf); }
       else { if (A.codes) SPMV_PIPE (double, true, A.val); else SPMV_PIPE (double, false, A.val); }
 #undef SPMV_PIPE
+      return;
+   }
+   if (T.spmv_variant == 9) {
+      if (A.valf) hipLaunchKernelGGL ((csr_spmv_rows_kernel<MODE, float>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st, A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.valf, x, y, b);
+      else hipLaunchKernelGGL ((csr_spmv_rows_kernel<MODE, double>), dim3 (per_xcd * 8), dim3 (SPMV_THREADS), 0, st, A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, A.val, x, y, b);
       return;
    }
    if (A.valf) {

@@ -63,10 +63,11 @@ def test_spmv_bit_exact_golden(golden):
     assert np.allclose(y, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())                # pin p3 (SciPy A@x)
 
 
-def test_spmv_bit_exact_medium(medium):
+@pytest.mark.parametrize("variant", [4, 0, 9])      # pipelined (default), plain stream, rows (stream staged in LDS, row lanes gather)
+def test_spmv_bit_exact_medium(medium, variant):
     p, blk = medium
     x = np.random.default_rng(3).standard_normal(p.flat_len)
-    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, restart=4, precond=solver.PRECOND_COLUMN_JACOBI) as s:
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, restart=4, precond=solver.PRECOND_COLUMN_JACOBI, tuning=dict(spmv_variant=variant)) as s:
         y = s.spmv(x)
         assert s.get_int("spmv_bytes") == 12 * p.nnz + 4 * (p.flat_len + 1) + 16 * p.flat_len
     assert np.array_equal(y, ora.spmv(p.rowptr, p.colind, p.nzval, x))
