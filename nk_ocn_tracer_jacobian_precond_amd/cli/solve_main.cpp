@@ -513,7 +513,17 @@ int main (int argc, char *argv[])
       int v;
       if (e && !parse_to_int ((char *) e, &v) && v > 1 && !use_comm) concurrency = v;
    }
-   if (concurrency > 1) {
+   // NKP_RHS_BLOCK=K (2..4, single-GPU flavour): K right-hand sides per nkp_solve call -- they share every sweep over the matrix
+   // and the hierarchy (nkp.h, nkp_solve_batch_device), each with its own recurrence and stopping test, so every tracer
+   // gets the bits of its own solve.  Written back in the order given, up to the first failure.
+   int rhs_block = 1;
+   {
+      const char *e = getenv ("NKP_RHS_BLOCK");
+      int v;
+      if (e && !parse_to_int ((char *) e, &v) && v > 1 && !use_comm) rhs_block = v > 4 ? 4 : v;
+   }
+   if (rhs_block > 1) concurrency = 1;
+   if (concurrency > 1 || rhs_block > 1) {
       std::vector<std::vector<char *>> groups;
       const char *sep = ",";
       for (char *var = strtok (vars, sep); var; var = strtok (NULL, sep)) {
@@ -536,8 +546,34 @@ int main (int argc, char *argv[])
          if (get_B_global (groups[g].data (), Bs[g].data ()))
             exit (EXIT_FAILURE);
       }
+      struct result { int info = 0, iters = 0; double berr = 0.0, relres = 0.0; std::string err; };
+      std::vector<result> res (ng);
       std::vector<nkp_solver *> handles (1, solver);
-      while (handles.size () < (size_t) concurrency && handles.size () < ng) {
+      if (rhs_block > 1) {
+         printf ("(%d) calling nkp_solve for %zu right-hand sides, %d per call\n", iam, ng, rhs_block);
+         fflush (stdout);
+         const size_t ldb = (size_t) (flat_len ? flat_len : 1);
+         std::vector<double> blockB ((size_t) rhs_block * ldb);
+         for (size_t g0 = 0; g0 < ng; g0 += (size_t) rhs_block) {
+            const int k = (int) (ng - g0 < (size_t) rhs_block ? ng - g0 : (size_t) rhs_block);
+            double berr_k[4] = { 0, 0, 0, 0 }, relres_k[4] = { 0, 0, 0, 0 };
+            int iters_k[4] = { 0, 0, 0, 0 };
+            for (int c = 0; c < k; c++) memcpy (blockB.data () + (size_t) c * ldb, Bs[g0 + c].data (), ldb * sizeof (double));
+            const int rc = nkp_solve (solver, blockB.data (), k, (int64_t) ldb, berr_k, iters_k, relres_k);
+            const std::string err = rc ? nkp_last_error () : "";
+            for (int c = 0; c < k; c++) {
+               result &r = res[g0 + c];
+               r.iters = iters_k[c]; r.berr = berr_k[c]; r.relres = relres_k[c];
+               // the call returns the worst column's code; a block with a failed column counts as failed from its first tracer on
+               // (nothing of the block is written: conservative next to the one-at-a-time loop, which would write the ones before it)
+               r.info = rc;
+               r.err = err;
+               if (rc >= 0) memcpy (Bs[g0 + c].data (), blockB.data () + (size_t) c * ldb, ldb * sizeof (double));
+            }
+            if (rc < 0) break;
+         }
+      }
+      while (rhs_block == 1 && handles.size () < (size_t) concurrency && handles.size () < ng) {
          nkp_solver *c = NULL;
          if (nkp_clone (solver, &c)) {            // out of device memory: run with what there is
             if (dbg_lvl)
@@ -546,12 +582,12 @@ int main (int argc, char *argv[])
          }
          handles.push_back (c);
       }
-      struct result { int info = 0, iters = 0; double berr = 0.0, relres = 0.0; std::string err; };
-      std::vector<result> res (ng);
-      printf ("(%d) calling nkp_solve for %zu right-hand sides, %zu in flight\n", iam, ng, handles.size ());
-      fflush (stdout);
+      if (rhs_block == 1) {
+         printf ("(%d) calling nkp_solve for %zu right-hand sides, %zu in flight\n", iam, ng, handles.size ());
+         fflush (stdout);
+      }
       std::vector<std::thread> workers;
-      for (size_t w = 0; w < handles.size (); w++)
+      for (size_t w = 0; rhs_block == 1 && w < handles.size (); w++)
          workers.emplace_back ([&, w] () {
             for (size_t g = w; g < ng; g += handles.size ()) {
                result &r = res[g];

@@ -9,6 +9,9 @@ from nk_ocn_tracer_jacobian_precond_amd import solver, synth
 
 pytestmark = pytest.mark.gpu
 
+# iteration bounds of the gen_A pipeline test: 1.3 x measured
+GEN_A_BOUNDS = {"upwind3": 96, "cent": 260}          # measured 74 / 199 (gpurun_out/r3m/genA2.log)
+
 
 def _solve(p, cnt=1, **kw):
     blk = solver.column_blocks(p.col_start(), p.tracer_state_len, cnt)
@@ -94,3 +97,42 @@ def test_centred_advection_at_1_degree():
     info = _solve(p, max_iters=2000)
     assert info["status"] == 0 and info["true_relres"] <= 1e-10, info
     assert info["iters"] <= 410, info                           # round 2 measured 315
+
+
+@pytest.mark.parametrize("adv,bound", [("upwind3", GEN_A_BOUNDS["upwind3"]), ("cent", GEN_A_BOUNDS["cent"])])
+def test_gen_A_pipeline_at_3_degrees(tmp_path, adv, bound):
+    """The reference's whole chain at the size of BASELINE configs[1] (3 degree x 60 levels): synthetic circulation file ->
+    bin/gen_A (src/gen_A.c, both the scheme of test/test_gen_A.csh and its default, centred advection) -> matrix file -> the
+    library on the GPU; the residual is recomputed by the CPU oracle on the CSR read back from the generated file."""
+    import os
+    import subprocess
+    from nk_ocn_tracer_jacobian_precond_amd import circ, nc3
+    BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nk_ocn_tracer_jacobian_precond_amd", "bin")
+    F, fills = circ.make_circulation(100, 116, 60, seed=0)
+    cpath, mpath = str(tmp_path / "circ.nc"), str(tmp_path / "matrix.nc")
+    circ.write_circ_file(cpath, F, fills, nc_type="float32")
+    (tmp_path / "gen_A.opt").write_text(f"circ_fname {cpath}\nadv_type {adv}\nl_adv_enforce_divfree 1\nhmix_type isop_file\nvmix_type file\n"
+                                        "sink_type const_shallow 365.0 10.0e2\n")
+    r = subprocess.run([os.path.join(BIN, "gen_A"), "-o", str(tmp_path / "gen_A.opt"), mpath], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    m = nc3.NcFile(mpath)
+    rp, ci, val = m.get("rowptr"), m.get("colind"), m.get("nzval_row_wise")
+    ii, jj, kk = (m.get(f"tracer_state_ind_to_{c}") for c in "ijk")
+    n = len(rp) - 1
+    assert n > 300_000
+    col_start = np.concatenate([np.flatnonzero(kk == 0), [len(kk)]]).astype(np.int32)
+    blk = solver.column_blocks(col_start, len(kk), 1)
+    cci, ccj = solver.column_coords(ii, jj, col_start, 1)
+    b = np.random.default_rng(1).standard_normal(n)
+    with solver.NkpSolver(rp, ci, val, blk, col_i=cci, col_j=ccj, max_iters=3000) as s:
+        x, info = s.solve(b, raise_on_fail=False)
+    relres = float(np.linalg.norm(b - ora.spmv(rp, ci, val, x)) / np.linalg.norm(b))
+    print(f"MEASURED gen_A 3 degree adv={adv} n={n} nnz={len(val)} iters={info['iters']} status={info['status']} relres={relres:.2e} berr={info['berr']:.2e}")
+    if adv == "cent":
+        # the centred matrix of this circulation file stops at 3e-10 in the 2-norm at a componentwise backward error of 1e-15
+        # (rows of very different size: the same status the coupled pair of test_gen_A_to_solve_pipeline gets); the library says
+        # so with NKP_OK_BERR instead of claiming the tolerance
+        assert info["status"] in (0, 3) and relres <= 1e-9 and info["berr"] <= 1e-14, (info, relres)
+    else:
+        assert info["status"] == 0 and relres <= 1e-10, (info, relres)
+    assert info["iters"] <= bound, info

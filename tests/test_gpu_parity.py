@@ -548,6 +548,24 @@ def test_cli_concurrent_right_hand_sides(tmp_path, golden_by_name):
     assert outs[0][0] != open(g.tracer_path, "rb").read()
 
 
+def test_cli_right_hand_sides_per_sweep(tmp_path, golden_by_name):
+    """NKP_RHS_BLOCK: the variable groups of one -v list go through nkp_solve several at a time, sharing the sweeps over the matrix;
+    every tracer has the bits of its own solve, so the file is byte-identical to the sequential loop's."""
+    g = golden_by_name("penta_12x10x6")
+    outs = []
+    for k, blockk in enumerate(("1", "2", "4")):
+        dst = str(tmp_path / f"B{k}.nc")
+        shutil.copy(g.tracer_path, dst)
+        env = dict(os.environ, NKP_RHS_BLOCK=blockk)
+        r = subprocess.run([os.path.join(BIN, "solve_ABglobal"), "-D1", "-v", ",".join(g.varnames), g.matrix_path, dst],
+                           capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr + r.stdout
+        outs.append((open(dst, "rb").read(), r.stdout))
+    assert "per call" in outs[1][1] and "per call" not in outs[0][1]
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert outs[0][0] != open(g.tracer_path, "rb").read()
+
+
 def test_chained_cycles_option(medium):
     """nkp_options.precond_steps: k multilevel cycles per Krylov iteration chained by defect correction against A.
     Same answer, fewer iterations; the automatic choice is one cycle at every size (round 2)."""
