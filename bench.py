@@ -71,6 +71,15 @@ def parse():
     return ap.parse_args()
 
 
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (the PMC passes are separate rocprofv3 runs, committed per round)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + suffix)))
+    if not found:
+        raise FileNotFoundError(suffix)
+    return found[-1]
+
+
 def host_cpu_share():
     """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands each job a
     share of its cores; OpenMP would otherwise start one spinning thread per core of the machine)."""
@@ -384,7 +393,7 @@ def main():
     # (FETCH_SIZE, WRITE_SIZE) and committed under profiles/; used only when it is this exact workload
     traffic = None
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r2_spmv_pmc.json")))
+        rec = json.load(open(latest_profile("spmv_pmc.json")))
         if rec.get("n") == n_global and rec.get("nnz") == p.nnz and not distributed:
             traffic = rec["traffic_bytes_per_launch"]
     except Exception:
@@ -403,7 +412,7 @@ def main():
     # HBM bytes per launch of those kernels from the PMC counters (separate rocprofv3 --pmc passes over tools/pmc_cycle.py,
     # committed under profiles/); attached only when it is this exact workload
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r2_cycle_pmc.json")))
+        rec = json.load(open(latest_profile("cycle_pmc.json")))
         if rec.get("n") == n_global and rec.get("nnz") == p.nnz and not distributed:
             for k in kernels:
                 for q in rec["kernels"]:

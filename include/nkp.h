@@ -123,6 +123,11 @@ typedef struct nkp_tuning {
    int setup_threads;        /* NKP_SETUP_THREADS (0 = automatic): host threads of the setup loops */
    int plan_times;           /* NKP_ML_PLAN_TIMES (0): print the split of the host-side aggregation */
    int ml_drop_intertracer;  /* NKP_ML_DROP_INTERTRACER (0): developer switch, hierarchy without inter-tracer couplings */
+   int dist_one_reduce;      /* NKP_DIST_ONE_REDUCE (0): distributed Arnoldi step with ONE allreduce -- the norm of the orthogonalised
+                                vector comes from the reduced multi-dot message (w.w - sum h^2) instead of a second allreduce.
+                                Off by default: the identity assumes an orthonormal basis, which one Gram-Schmidt pass keeps only
+                                to 1e-6 or so, and the solve pays for it (2 ranks, 40x46x20: 48 iterations against 45) -- more than
+                                the 20-30 us allreduce it saves per 3 ms step */
    int batch_spmv_rows;      /* NKP_BATCH_SPMV_ROWS (1): batched SpMV stages the (value, column) stream in LDS and lets each row's lane gather
                                 its own K-wide rows of x; 0 = products parked in LDS, K / 2 passes */
 } nkp_tuning;

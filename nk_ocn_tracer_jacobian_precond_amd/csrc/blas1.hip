@@ -323,6 +323,32 @@ void finish_column_kernel (double *__restrict__ h, const double *__restrict__ h2
    }
 }
 
+// distributed flavour: ||w - V h||^2 = w.w - sum h_i^2 from the ALREADY reduced multi-dot message (h[0..k-1], h[k] = w.w), so
+// that an Arnoldi step needs one allreduce instead of two.  The difference loses log10 (w.w / result) digits; below 1e-8 of
+// w.w (the new direction is numerically inside the old space) h[k] is returned NEGATIVE: the host takes its magnitude and ends
+// the restart cycle there, and the true residual of the restart decides.  One wave, fixed order.
+__global__ __launch_bounds__ (NKP_WAVE)
+void finish_column_pythagoras_kernel (double *__restrict__ h, int k, double *__restrict__ inv)
+{
+   double s = 0.0;
+   for (int j = threadIdx.x; j < k; j += NKP_WAVE) s += h[j] * h[j];
+   for (int off = NKP_WAVE / 2; off > 0; off >>= 1) s += __shfl_down (s, off);
+   if (threadIdx.x == 0) {
+      const double ww = h[k];
+      double t2 = ww - s;
+      const bool weak = !(t2 >= 1e-8 * ww);
+      if (!(t2 > 0.0)) t2 = 0.0;
+      const double t = sqrt (t2);
+      h[k] = weak ? -t : t;
+      inv[0] = (t > 0.0) ? 1.0 / t : 0.0;
+   }
+}
+
+void launch_finish_column_pythagoras (double *h, int k, double *inv, hipStream_t st)
+{
+   hipLaunchKernelGGL (finish_column_pythagoras_kernel, dim3 (1), dim3 (NKP_WAVE), 0, st, h, k, inv);
+}
+
 void launch_finish_column (double *h, const double *h2, int k, const double *nrm2, double *inv, hipStream_t st)
 {
    hipLaunchKernelGGL (finish_column_kernel, dim3 (1), dim3 (NKP_WAVE), 0, st, h, h2, k, nrm2, inv);

@@ -139,6 +139,7 @@ void launch_berr (const double *r, const double *den, int64_t n, double *partial
 // small device-side scalar programs of the Krylov drivers
 // h[j] += h2[j] (j<k); h[k] = sqrt(nrm2); inv[0] = 1/h[k] (0 if h[k]==0)
 void launch_finish_column (double *h, const double *h2, int k, const double *nrm2, double *inv, hipStream_t st);
+void launch_finish_column_pythagoras (double *h, int k, double *inv, hipStream_t st);
 // y = a*x + b*y style helpers for BiCGStab
 void launch_axpby (double a, const double *x, double b, double *y, int64_t n, hipStream_t st);
 void launch_copy (const double *x, double *y, int64_t n, hipStream_t st);

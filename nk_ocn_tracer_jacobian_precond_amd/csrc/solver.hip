@@ -86,7 +86,7 @@ static void builtin_tuning (nkp_tuning *t)
    t->col_ldsres = 2; t->col_stream = 1; t->col_stream_min = -1; t->col_stream_gw = 32; t->col_wave_max = 8192; t->col_w3 = 1;
    t->col_group = 8; t->col_pipe_min = 0; t->col_ldsres_early = 0; t->col_ldsres_packed = 1;
    t->spmv_variant = 4; t->spmv_compress = 0; t->spmv_pipe_min = 1024; t->spmv_run = 1; t->spmv_wgs = 256;
-   t->rhs_batch = 1; t->batch_spmv_rows = 1; t->precond_steps = 0; t->equil = -1; t->dist_overlap = 1; t->dist_ras = 1; t->force_dist = 0; t->setup_threads = 0; t->plan_times = 0;
+   t->rhs_batch = 1; t->batch_spmv_rows = 1; t->precond_steps = 0; t->equil = -1; t->dist_overlap = 1; t->dist_ras = 1; t->dist_one_reduce = 0; t->force_dist = 0; t->setup_threads = 0; t->plan_times = 0;
    t->ml_drop_intertracer = 0;
 }
 
@@ -123,7 +123,7 @@ extern "C" int nkp_default_tuning (nkp_tuning *t)
    ENV_POS ("NKP_SPMV_RUN", spmv_run); ENV_POS ("NKP_SPMV_WGS", spmv_wgs);
    ENV_FLAG ("NKP_RHS_BATCH", rhs_batch); ENV_FLAG ("NKP_BATCH_SPMV_ROWS", batch_spmv_rows);
    ENV_POS ("NKP_PRECOND_STEPS", precond_steps); ENV_FLAG ("NKP_EQUIL", equil);
-   ENV_FLAG ("NKP_DIST_OVERLAP", dist_overlap); ENV_FLAG ("NKP_DIST_RAS", dist_ras);
+   ENV_FLAG ("NKP_DIST_OVERLAP", dist_overlap); ENV_FLAG ("NKP_DIST_RAS", dist_ras); ENV_FLAG ("NKP_DIST_ONE_REDUCE", dist_one_reduce);
    if (getenv ("NKP_FORCE_DIST")) t->force_dist = 1;
    ENV_POS ("NKP_SETUP_THREADS", setup_threads);
    if (getenv ("NKP_ML_PLAN_TIMES")) t->plan_times = 1;
@@ -798,6 +798,9 @@ static void arnoldi_orthogonalise (nkp_solver *s, int j)
       launch_update_w (s->V, s->vf32, ld, j + 1, s->h2_dev (), s->w, s->n, s->partial, s->misc_dev (), s->stream);
       allreduce_dev (s, s->misc_dev (), 1, 0);
       launch_finish_column (s->h_dev (), s->h2_dev (), j + 1, s->misc_dev (), s->misc_dev () + 1, s->stream);
+   } else if (s->dist.on && s->tune.dist_one_reduce) {
+      // ||w||^2 after the update from the message that is already reduced (w.w rode along with the dots): one allreduce per step
+      launch_finish_column_pythagoras (s->h_dev (), j + 1, s->misc_dev () + 1, s->stream);
    } else {
       allreduce_dev (s, s->misc_dev (), 1, 0);
       launch_finish_column (s->h_dev (), nullptr, j + 1, s->misc_dev (), s->misc_dev () + 1, s->stream);
@@ -913,6 +916,9 @@ static bool fg_post_step (nkp_solver *s, FgmresState &F)
    const int m = s->m, j = F.j;
    double *hc = &F.H[(size_t) j * (m + 1)];
    for (int i = 0; i <= j + 1; i++) hc[i] = s->hpin[i];
+   // a negative sub-diagonal entry is finish_column_pythagoras_kernel's mark: its magnitude is short of digits, the cycle ends here
+   const bool weak_norm = hc[j + 1] < 0.0;
+   if (weak_norm) hc[j + 1] = -hc[j + 1];
    for (int i = 0; i < j; i++) {
       const double t = F.cs[i] * hc[i] + F.sn[i] * hc[i + 1];
       hc[i + 1] = -F.sn[i] * hc[i] + F.cs[i] * hc[i + 1];
@@ -936,7 +942,7 @@ static bool fg_post_step (nkp_solver *s, FgmresState &F)
       F.est_at_exit = est * (F.beta / F.beta_it);
       return true;
    }
-   return F.j >= m || F.its >= s->opt.max_iters;
+   return weak_norm || F.j >= m || F.its >= s->opt.max_iters;
 }
 
 // y = H^-1 g (upper triangular, size F.j), x += Z y; after a breakdown the true residual of what we have decides

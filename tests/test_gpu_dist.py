@@ -25,6 +25,18 @@ def test_distributed_solve(tmp_path, world):
     assert res[0]["iters"] <= plain[0]["iters"], (res[0]["iters"], plain[0]["iters"])     # the overlap is there to save iterations
 
 
+def test_one_allreduce_per_arnoldi_step(tmp_path):
+    """nkp_tuning.dist_one_reduce (opt-in): the norm of the orthogonalised vector comes out of the reduced multi-dot message
+    (w.w - sum h^2) instead of a second allreduce.  It converges to the same tolerance; the iterations it costs (the identity
+    assumes an orthonormal basis, single-pass Gram-Schmidt keeps it only approximately) are why it is not the default."""
+    two = launch(2, "gpu-solve", str(tmp_path / "two"), extra=("--grid", "40x46x20"))
+    one = launch(2, "gpu-solve", str(tmp_path / "one"), extra=("--grid", "40x46x20"), env_extra={"NKP_DIST_ONE_REDUCE": "1"})
+    for res in (one, two):
+        assert all(r["status"] == 0 and r["relres"] <= 1e-10 and not r["comm_errors"] for r in res), res
+        assert res[0]["relres_checked"] <= 1.1e-10
+    assert two[0]["iters"] - 2 <= one[0]["iters"] <= two[0]["iters"] * 1.25 + 2, (one[0]["iters"], two[0]["iters"])
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_solve_one_tracer_per_rank(tmp_path, world):
     """Weak-scaling layout: rank t holds tracer t of a `world`-tracer coupled system (its preconditioner ignores the

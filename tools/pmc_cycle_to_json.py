@@ -27,7 +27,7 @@ rec = {"workload": "320x384x60 upwind3+isop (K33), fine level, one colour", "n":
        "calibration": {"kernel": "scale_to_kernel", "FETCH_SIZE_KB": cal_f, "algorithmic_read_KB": info["n"] * 8 / 1024.0,
                        "fetch_factor": info["n"] * 8 / 1024.0 / cal_f}, "kernels": []}
 for prefix, key, ms in (("void csr_spmv_pipe_kernel<1, float", "smoother_spmv_bytes", "smoother_ms"),
-                        ("void colblock_apply_ldsres_kernel<2, float", "column_solve_bytes", "column_ms")):
+                        ("void colblock_apply_ldspack_kernel<2", "column_solve_bytes", "column_ms")):
     names = [k for k in fetch if k.startswith(prefix)]
     if not names:
         raise SystemExit(f"kernel {prefix} not found in {list(fetch)[:10]}")
