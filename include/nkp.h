@@ -76,8 +76,8 @@ typedef struct nkp_tuning {
    int ml_split;             /* NKP_ML_SPLIT (1): connectivity-aware coarse cells inside the geometric groups */
    int ml_pocket;            /* NKP_ML_POCKET (4): same-depth connected sets of at most that many cells become one coarse cell */
    int ml_big_from;          /* NKP_ML_BIG_FROM (-3 = automatic): 4 x 4 groups from that level on, -1 = never */
-   int ml_coarsest_rows;     /* NKP_ML_COARSEST_ROWS (3000): stop coarsening at that many rows */
-   int ml_dense_max;         /* NKP_ML_DENSE_MAX (6000): largest last level solved with a dense inverse */
+   int ml_coarsest_rows;     /* NKP_ML_COARSEST_ROWS (8000): stop coarsening at that many rows (a dense level costs its bytes, an iterated one ~200 us of launch latencies) */
+   int ml_dense_max;         /* NKP_ML_DENSE_MAX (8192): largest last level solved with a dense inverse */
    double ml_theta;          /* NKP_ML_THETA (0): edge threshold of the connectivity test */
    double ml_tau;            /* NKP_ML_TAU (0.01): leaf-stub threshold */
    int64_t ml_device_min;    /* NKP_ML_DEVICE_MIN (100000): levels with at least that many rows are built by the setup kernels,

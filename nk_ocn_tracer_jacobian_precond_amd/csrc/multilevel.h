@@ -35,6 +35,8 @@ struct MlHierarchy {
    std::vector<MlLevel> lev;
    int *perm0 = nullptr;        // level-0 row i holds original row perm0[i]
    double *coarse_inv = nullptr;   // dense inverse of the coarsest operator (row-major)
+   float *coarse_invf = nullptr;   // f32 storage mode: the copy the cycle multiplies with (rows padded to coarse_ldf)
+   int coarse_ldf = 0;
    int nu = 1;                  // Gauss-Seidel sweeps before and after the coarse correction
    int nu_coarse = 1;           // ... on levels >= coarse_from
    int coarse_from = 2;

@@ -1145,14 +1145,27 @@ int finalize_host_level (MlHierarchy &H, int l, int nlev, Nat &N, Nat *Cn, int v
    }
    if (dense_last) {
       // coarsest level: dense inverse (permuted order)
-      std::vector<double> dense ((size_t) nl * nl, 0.0);
-      for (int64_t i = 0; i < nl; i++)
-         for (int e = prow[i]; e < prow[i + 1]; e++) dense[(size_t) i * nl + pcol[e]] = pval[e];
+      std::vector<double> dense;
+      auto fill_dense = [&] () {
+         dense.assign ((size_t) nl * nl, 0.0);
+         for (int64_t i = 0; i < nl; i++)
+            for (int e = prow[i]; e < prow[i + 1]; e++) dense[(size_t) i * nl + pcol[e]] = pval[e];
+      };
       if (H.tune->ml_host_inverse) {
+         fill_dense ();
          if (!dense_inverse ((int) nl, dense)) ML_FAIL (-4, "multilevel setup: coarsest operator is singular");
          if (!upload (&H.coarse_inv, dense.data (), dense.size (), &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
-      } else if (!dense_inverse_device ((int) nl, dense, &H.coarse_inv, &H.device_bytes, st))
-         ML_FAIL (-4, "multilevel setup: coarsest operator is singular (or the device is out of memory)");
+      } else {
+         // blocked elimination on the matrix cores (dense.hip); a pivot it does not trust sends the level to the pivoted routine
+         auto t_inv0 = setup_clk::now ();
+         const int brc = dense_inverse_blocked_device ((int) nl, prow.data (), pcol.data (), pval.data (), &H.coarse_inv, H.f32 ? &H.coarse_invf : nullptr,
+                                                       &H.coarse_ldf, &H.device_bytes, st);
+         if (brc < 0) ML_FAIL (-2, "multilevel setup: device allocation failed (dense inverse of %lld rows)", (long long) nl);
+         if (verbose) printf ("(%d) multilevel: dense inverse of %lld rows: %s, %.3f s\n", rank, (long long) nl, brc == 0 ? "blocked elimination" : "a pivot too small for it, pivoted routine instead", secs_since (t_inv0));
+         if (brc > 0) fill_dense ();
+         if (brc > 0 && !dense_inverse_device ((int) nl, dense, &H.coarse_inv, &H.device_bytes, st))
+            ML_FAIL (-4, "multilevel setup: coarsest operator is singular (or the device is out of memory)");
+      }
    }
    if (verbose)
       printf ("(%d) multilevel: level %d: %lld rows, %lld entries, %d columns (%d + %d by colour)%s\n", rank, l, (long long) nl,
@@ -1479,6 +1492,8 @@ void ml_free (MlHierarchy &H)
    H.lev.clear ();
    if (H.perm0) (void) hipFree (H.perm0);
    if (H.coarse_inv) (void) hipFree (H.coarse_inv);
+   if (H.coarse_invf) (void) hipFree (H.coarse_invf);
+   H.coarse_invf = nullptr;
    H.perm0 = nullptr;
    H.coarse_inv = nullptr;
 }
@@ -1526,7 +1541,8 @@ static void ml_cycle (MlHierarchy &H, int l, hipStream_t st)
    if (l == H.tail_from && H.coarse_inv && H.gamma_to <= H.gamma_from && ml_tail_launch (H, l, st) == 0) return;
    if (l == (int) H.lev.size () - 1) {
       if (H.coarse_inv) {
-         launch_dense_matvec (H.coarse_inv, V.b, V.x, (int) V.n, st);
+         if (H.coarse_invf) launch_dense_matvec_f32 (H.coarse_invf, H.coarse_ldf, V.b, V.x, (int) V.n, st);
+         else launch_dense_matvec (H.coarse_inv, V.b, V.x, (int) V.n, st);
          return;
       }
       // no dense inverse: many sweeps of the column smoother from x = 0 (what is left here is diagonally dominant)
@@ -1621,7 +1637,8 @@ static void ml_cycle_batch (MlHierarchy &H, int K, int l, hipStream_t st)
    V.bcur[0] = V.bcur[1] = 0;
    if (l == (int) H.lev.size () - 1) {
       if (H.coarse_inv) {
-         launch_dense_matvec_batch (K, H.coarse_inv, V.bb, V.bx, (int) V.n, st);
+         if (H.coarse_invf) launch_dense_matvec_f32_batch (K, H.coarse_invf, H.coarse_ldf, V.bb, V.bx, (int) V.n, st);
+         else launch_dense_matvec_batch (K, H.coarse_inv, V.bb, V.bx, (int) V.n, st);
          return;
       }
       const int sweeps = H.tune->ml_coarsest_sweeps > 0 ? H.tune->ml_coarsest_sweeps : 30;

@@ -158,6 +158,10 @@ void launch_gather (const int *perm, const double *in, double *out, int64_t n, h
 void launch_scatter (const int *perm, const double *in, double *out, int64_t n, hipStream_t st);
 // y = Minv x, dense row-major n x n (coarsest level)
 void launch_dense_matvec (const double *Minv, const double *x, double *y, int n, hipStream_t st);
+void launch_dense_matvec_f32 (const float *Minv, int ld, const double *x, double *y, int n, hipStream_t st);
+void launch_dense_matvec_f32_batch (int K, const float *Minv, int ld, const double *x, double *y, int n, hipStream_t st);
+int dense_inverse_blocked_device (int n, const int *h_rowptr, const int *h_col, const double *h_val, double **inv_out, float **invf_out, int *ldf_out,
+                                  size_t *bytes, hipStream_t st);
 
 // ---------------------------------------------------------------- K interleaved right-hand sides (batch.hip; X[i * K + k], K = 2 or 4)
 void launch_interleave (int K, const double *const *src /* K pointers, NULL = zeros */, double *X, int64_t n, hipStream_t st);

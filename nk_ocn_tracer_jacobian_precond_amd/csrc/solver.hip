@@ -79,7 +79,7 @@ static void builtin_tuning (nkp_tuning *t)
 {
    memset (t, 0, sizeof *t);
    t->struct_size = (int) sizeof (nkp_tuning);
-   t->ml_split = 1; t->ml_pocket = 4; t->ml_big_from = -3; t->ml_coarsest_rows = 3000; t->ml_dense_max = 6000;
+   t->ml_split = 1; t->ml_pocket = 4; t->ml_big_from = -3; t->ml_coarsest_rows = 8000; t->ml_dense_max = 8192;
    t->ml_theta = 0.0; t->ml_tau = 0.01; t->ml_device_min = 100000;
    t->ml_smooth_coarse = 0; t->ml_coarse_from = 2; t->ml_gamma_from = 0; t->ml_gamma_to = 0; t->ml_f32 = 1; t->ml_host_inverse = 0;
    t->ml_fused = 0; t->ml_fused_max_cols = 0; t->ml_wave_fused = 1; t->ml_coarsest_sweeps = 30; t->ml_tail_rows = 0; t->ml_omega = 1.1;
@@ -589,7 +589,7 @@ static int create_impl (nkp_solver **out, const nkp_options *opt_in, int64_t n, 
          colind = f_colind.data ();
          val = f_val.data ();
       }
-      const int coarsest_rows = tune.ml_coarsest_rows;   // 3000: dense inverse on the device, one tiny level less at 3 degrees, cycle 1.15 -> 0.96 ms
+      const int coarsest_rows = tune.ml_coarsest_rows;   // 8000: a dense last level costs its bytes, an iterated one ~200 us of launch latencies (dense.hip)
       const int mrc = pm ? ml_setup (s->ml, pm->n, pm->rowptr, pm->colind, pm->val, pm->blk_start, pm->nblk, pm->col_i, pm->col_j, pm->col_t, coupled_tracer_cnt, opt.ml_levels,
                                      opt.ml_smooth, coarsest_rows, opt.verbose, opt.rank, s->stream, err, sizeof err, s->tune)
                          : ml_setup (s->ml, n, rowptr, colind, val, blk_start, nblk, blk_default.empty () ? opt.col_i : nullptr, blk_default.empty () ? opt.col_j : nullptr, blk_default.empty () ? opt.col_t : nullptr,

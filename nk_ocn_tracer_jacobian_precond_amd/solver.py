@@ -129,7 +129,7 @@ def load_library(path=None):
     return lib
 
 
-def ml_plan_host(rowptr, colind, val, blk_start, col_i=None, col_j=None, coupled_tracer_cnt=1, max_levels=0, coarsest_rows=3000):
+def ml_plan_host(rowptr, colind, val, blk_start, col_i=None, col_j=None, coupled_tracer_cnt=1, max_levels=0, coarsest_rows=8000):
     """nkp_ml_plan_host: the coarse cells of every level of the multilevel preconditioner (host only, no GPU needed).
     Returns (rows per level, [cmap of level l -> l+1], [column block of every row of level l+1])."""
     lib = load_library()

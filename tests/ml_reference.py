@@ -120,7 +120,7 @@ def split_groups(L, I, J, ck, colid, pocket=4, theta=0.0, tau=0.01):
     return inv, gI[colraw], gJ[colraw], uk % 4096, colid2
 
 
-def build(A, ci, cj, ck, colid, nu=3, coarsest_rows=3000, big_from=3, max_levels=12, split=True):
+def build(A, ci, cj, ck, colid, nu=3, coarsest_rows=8000, big_from=3, max_levels=12, split=True):
     levels = []
     L = low_order(A, colid)
     lvl = 0

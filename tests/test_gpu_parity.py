@@ -768,17 +768,50 @@ def test_wave_per_column_on_small_levels_is_bit_identical(case, medium, monkeypa
 
 
 def test_device_dense_inverse_matches_host(medium, monkeypatch):
-    """The coarsest level's dense inverse is computed on the device (Gauss-Jordan, four small launches per step) with the
-    host routine's operations: the cycle must not change by a bit."""
+    """The coarsest level's dense inverse is computed on the device by blocked Gauss-Jordan on the f64 matrix cores (csrc/dense.hip):
+    checked against the level's own operator (inverse x operator = identity), against the host routine (pivoted, unblocked) through
+    the cycle, and -- f32 storage mode multiplies with an f32 copy -- within f32 rounding there."""
+    import scipy.sparse as sp
     p, blk = medium
     ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
     r = np.random.default_rng(43).standard_normal(p.flat_len)
-    z = {}
-    for host in ("1", "0"):
-        monkeypatch.setenv("NKP_ML_HOST_INVERSE", host)
-        with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, restart=4) as s:
-            z[host] = s.precond_apply(r)
-    assert np.array_equal(z["0"], z["1"]), np.abs(z["0"] - z["1"]).max()
+    for f32, tol in (("0", 1e-11), ("1", 1e-5)):
+        monkeypatch.setenv("NKP_ML_F32", f32)
+        z = {}
+        for host in ("1", "0"):
+            monkeypatch.setenv("NKP_ML_HOST_INVERSE", host)
+            with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, restart=4) as s:
+                z[host] = s.precond_apply(r)
+                if host == "0" and f32 == "0":
+                    last = s.get_int("levels") - 1
+                    rp, cc, vv = s.ml_level_array(last, "rowptr"), s.ml_level_array(last, "colind"), s.ml_level_array(last, "val")
+                    n = len(rp) - 1
+                    inv = s.ml_level_array(last, "coarse_inv").reshape(n, n)
+                    L = sp.csr_matrix((vv, cc, rp), shape=(n, n))
+                    assert n > 64                                          # more than one block of the elimination
+                    assert np.abs(inv @ L.toarray() - np.eye(n)).max() <= 1e-10
+        assert np.linalg.norm(z["0"] - z["1"]) <= tol * np.linalg.norm(z["1"]), (f32, np.linalg.norm(z["0"] - z["1"]) / np.linalg.norm(z["1"]))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 200, 1000])
+def test_blocked_dense_inverse_sizes(n):
+    """Block-size edges of the blocked elimination: a one-level 'hierarchy' whose only level is solved by its dense inverse
+    (tridiagonal-plus-random diagonally dominant operators of 1 .. 1000 rows, single-row water columns)."""
+    rng = np.random.default_rng(n)
+    import scipy.sparse as sp
+    A = sp.random(n, n, density=min(1.0, 6.0 / n), random_state=int(n), format="csr")
+    A = -abs(A) - abs(A.T)
+    A = (A - sp.diags(np.asarray(A.sum(axis=1)).ravel() - 1.0 - rng.random(n))).tocsr()
+    A = (-A).tocsr()                                  # the sign of an ocean Jacobian: negative diagonal (the twin keeps such a matrix as it is)
+    A.sort_indices()
+    blk = np.arange(n + 1, dtype=np.int32)
+    b = rng.standard_normal(n)
+    with solver.NkpSolver(A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, blk, col_i=np.arange(n, dtype=np.int32), col_j=np.zeros(n, np.int32),
+                          restart=10, tuning=dict(ml_f32=0)) as s:
+        assert s.get_int("levels") == 1
+        z = s.precond_apply(b)
+    x = np.linalg.solve(A.toarray(), b)
+    assert np.linalg.norm(z - x) <= 1e-10 * np.linalg.norm(x)
 
 
 def test_graft_entry_smoke():

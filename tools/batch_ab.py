@@ -18,8 +18,9 @@ for arg in sys.argv[1:]:
     for kv in filter(None, spec.split(",")):
         k, _, v = kv.partition(":")
         tune[k] = float(v) if "." in v else int(v)
+    t0 = time.perf_counter()
     with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, col_i=ci, col_j=cj, tuning=tune) as s:
-        out = dict(name=name, tune=tune)
+        out = dict(name=name, tune=tune, create_s=time.perf_counter() - t0, levels=s.get_int("levels"), precond_ms=s.time_kernel(1, reps=20))
         for rep in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             its = []
