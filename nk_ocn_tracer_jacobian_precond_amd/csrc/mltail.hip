@@ -37,6 +37,8 @@ struct TailArgs {
    int nlev;                          // levels in the tail, the last one is the dense coarsest level
    double omega;
    const double *coarse_inv;
+   const float *coarse_invf;      // f32 storage mode: the copy the cycle multiplies with (rows padded to coarse_ldf), else NULL
+   int coarse_ldf;
    TailLevel lev[TAIL_MAX_LEVELS];
 };
 
@@ -178,9 +180,22 @@ void ml_tail_kernel (TailArgs A)
       const TailLevel &V = A.lev[last];
       const int lane = threadIdx.x & (NKP_WAVE - 1), wave = threadIdx.x / NKP_WAVE;
       for (int row = wave; row < V.n; row += TAIL_THREADS / NKP_WAVE) {
-         const double *m = A.coarse_inv + (int64_t) row * V.n;
          double acc = 0.0;
-         for (int c = lane; c < V.n; c += NKP_WAVE) acc += m[c] * V.b[c];
+         if (A.coarse_invf) {
+            // f32 copy of the inverse, summed like dense_matvec_f32_kernel (dense.hip): four consecutive columns per lane and step
+            const float4 *m4 = reinterpret_cast<const float4 *> (A.coarse_invf + (int64_t) row * A.coarse_ldf);
+            for (int c4 = lane; c4 * 4 < V.n; c4 += NKP_WAVE) {
+               const float4 v = m4[c4];
+               const int c = c4 * 4;
+               acc += (double) v.x * V.b[c];
+               if (c + 1 < V.n) acc += (double) v.y * V.b[c + 1];
+               if (c + 2 < V.n) acc += (double) v.z * V.b[c + 2];
+               if (c + 3 < V.n) acc += (double) v.w * V.b[c + 3];
+            }
+         } else {
+            const double *m = A.coarse_inv + (int64_t) row * V.n;
+            for (int c = lane; c < V.n; c += NKP_WAVE) acc += m[c] * V.b[c];
+         }
          acc = tail_wave_sum (acc);
          if (lane == 0) V.x[row] = acc;
       }
@@ -206,6 +221,8 @@ int ml_tail_launch (MlHierarchy &H, int l0, hipStream_t st)
    A.nlev = nlev;
    A.omega = H.omega;
    A.coarse_inv = H.coarse_inv;
+   A.coarse_invf = H.coarse_invf;
+   A.coarse_ldf = H.coarse_ldf;
    for (int q = 0; q < nlev; q++) {
       MlLevel &V = H.lev[l0 + q];
       TailLevel &T = A.lev[q];
