@@ -9,6 +9,8 @@
 // vectors and every basis vector exactly once.
 #include "nkp_dev.h"
 
+#include <stdint.h>
+
 #define B1_THREADS 256
 
 __device__ __forceinline__ double wave_sum (double v)
@@ -234,10 +236,26 @@ void launch_copy (const double *x, double *y, int64_t n, hipStream_t st)
    (void) hipMemcpyAsync (y, x, (size_t) n * sizeof (double), hipMemcpyDeviceToDevice, st);
 }
 
+// zero fill in ONE launch: hipMemsetAsync splits a buffer whose size is not a multiple of its block into two kernels (an aligned
+// body and a 256-thread remainder), ~10 us of launch floors per level of the cycle instead of ~5
+__global__ __launch_bounds__ (B1_THREADS)
+void zero_kernel (double *__restrict__ y, int64_t n)
+{
+   const int64_t stride = (int64_t) gridDim.x * B1_THREADS * 2;
+   for (int64_t i = ((int64_t) blockIdx.x * B1_THREADS + threadIdx.x) * 2; i < n; i += stride) {
+      if (i + 1 < n) *reinterpret_cast<double2 *> (y + i) = make_double2 (0.0, 0.0);       // vectors are 16-byte aligned (hipMalloc, even offsets)
+      else y[i] = 0.0;
+   }
+}
+
 void launch_fill (double *y, double v, int64_t n, hipStream_t st)
 {
-   if (v == 0.0) (void) hipMemsetAsync (y, 0, (size_t) n * sizeof (double), st);
-   else launch_axpby (v, nullptr, 0.0, y, n, st);
+   if (n <= 0) return;
+   if (v == 0.0) {
+      if ((reinterpret_cast<uintptr_t> (y) & 15) == 0) hipLaunchKernelGGL (zero_kernel, dim3 (red_grid (n) * 2), dim3 (B1_THREADS), 0, st, y, n);
+      else (void) hipMemsetAsync (y, 0, (size_t) n * sizeof (double), st);
+   } else
+      launch_axpby (v, nullptr, 0.0, y, n, st);
 }
 
 // ---------------------------------------------------------------- dot, berr

@@ -214,29 +214,61 @@ int dense_inverse_blocked_device (int n, const int *h_rowptr, const int *h_col, 
 }
 
 // ---------------------------------------------------------------- y = M x with the f32 copy: one wave per row, 16-byte loads
+// Summation order (fixed, the tail kernel of mltail.hip repeats it): lane l owns the column quads l, l + 64, ...; a quad adds its
+// four products in column order; then the 64 partial sums go through the shuffle tree.  DMV_UNROLL quads are requested before the
+// first is used (the first version had one load in flight per lane: 74 us for the 206 MB of the 1 degree level, 2.8 TB/s).
+#define DMV_UNROLL 4
+#define DMV_ROWS 4
+// ... and a wave takes DMV_ROWS rows at once: the loads of x (32 bytes per quad and lane, from L1/L2 -- x is 57 KB) were two thirds
+// of the L1 requests of the one-row kernel; four rows share them.  Measured for the 206 MB of the 1 degree level (rows x quads in
+// flight per lane): 1 x 1 75 us, 1 x 8 80, 4 x 4 **64**, 2 x 8 75, 8 x 2 80, 4 x 8 117 (256 VGPRs), x staged in LDS by 16-wave workgroups 69 --
+// the matrix stream itself does not get past 3.2 TB/s in this one-shot launch; 4 x 4 stays.
 __global__ __launch_bounds__ (256)
 void dense_matvec_f32_kernel (const float *__restrict__ M, int ld, const double *__restrict__ x, double *__restrict__ y, int n)
 {
-   const int row = (int) ((blockIdx.x * 256 + threadIdx.x) / NKP_WAVE);
+   const int row0 = (int) ((blockIdx.x * 256 + threadIdx.x) / NKP_WAVE) * DMV_ROWS;
    const int lane = threadIdx.x & (NKP_WAVE - 1);
-   if (row >= n) return;
-   const float4 *m = reinterpret_cast<const float4 *> (M + (size_t) row * ld);
-   double acc = 0.0;
-   for (int c4 = lane; c4 * 4 < n; c4 += NKP_WAVE) {
-      const float4 v = m[c4];
-      const int c = c4 * 4;
-      acc += (double) v.x * x[c];
-      if (c + 1 < n) acc += (double) v.y * x[c + 1];
-      if (c + 2 < n) acc += (double) v.z * x[c + 2];
-      if (c + 3 < n) acc += (double) v.w * x[c + 3];
+   if (row0 >= n) return;
+   const float4 *m[DMV_ROWS];
+#pragma unroll
+   for (int r = 0; r < DMV_ROWS; r++) m[r] = reinterpret_cast<const float4 *> (M + (size_t) (row0 + r < n ? row0 + r : n - 1) * ld);
+   const int nq = (n + 3) >> 2;                       // quads of a row (ld is a multiple of 4, the tail of the last quad is zero)
+   double acc[DMV_ROWS];
+#pragma unroll
+   for (int r = 0; r < DMV_ROWS; r++) acc[r] = 0.0;
+   for (int q0 = lane; q0 < nq; q0 += NKP_WAVE * DMV_UNROLL) {
+      float4 v[DMV_ROWS][DMV_UNROLL];
+#pragma unroll
+      for (int u = 0; u < DMV_UNROLL; u++) {
+         const int q = q0 + u * NKP_WAVE;
+#pragma unroll
+         for (int r = 0; r < DMV_ROWS; r++) v[r][u] = q < nq ? m[r][q] : make_float4 (0.0f, 0.0f, 0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int u = 0; u < DMV_UNROLL; u++) {
+         const int c = (q0 + u * NKP_WAVE) * 4;
+         const double x0 = c < n ? x[c] : 0.0, x1 = c + 1 < n ? x[c + 1] : 0.0, x2 = c + 2 < n ? x[c + 2] : 0.0, x3 = c + 3 < n ? x[c + 3] : 0.0;
+#pragma unroll
+         for (int r = 0; r < DMV_ROWS; r++) {
+            if (c < n) acc[r] += (double) v[r][u].x * x0;
+            if (c + 1 < n) acc[r] += (double) v[r][u].y * x1;
+            if (c + 2 < n) acc[r] += (double) v[r][u].z * x2;
+            if (c + 3 < n) acc[r] += (double) v[r][u].w * x3;
+         }
+      }
    }
-   for (int off = NKP_WAVE / 2; off > 0; off >>= 1) acc += __shfl_down (acc, off);
-   if (lane == 0) y[row] = acc;
+#pragma unroll
+   for (int r = 0; r < DMV_ROWS; r++) {
+      double a = acc[r];
+      for (int off = NKP_WAVE / 2; off > 0; off >>= 1) a += __shfl_down (a, off);
+      if (lane == 0 && row0 + r < n) y[row0 + r] = a;
+   }
 }
 
 void launch_dense_matvec_f32 (const float *Minv, int ld, const double *x, double *y, int n, hipStream_t st)
 {
-   if (n > 0) hipLaunchKernelGGL (dense_matvec_f32_kernel, dim3 ((n + 3) / 4), dim3 (256), 0, st, Minv, ld, x, y, n);
+   const int waves = (n + DMV_ROWS - 1) / DMV_ROWS;
+   if (n > 0) hipLaunchKernelGGL (dense_matvec_f32_kernel, dim3 ((waves + 3) / 4), dim3 (256), 0, st, Minv, ld, x, y, n);
 }
 
 // K interleaved right-hand sides; every column accumulates exactly like the single-vector kernel above
@@ -248,18 +280,28 @@ void dense_matvec_f32_batch_kernel (const float *__restrict__ M, int ld, const d
    const int lane = threadIdx.x & (NKP_WAVE - 1);
    if (row >= n) return;
    const float4 *m = reinterpret_cast<const float4 *> (M + (size_t) row * ld);
+   const int nq = (n + 3) >> 2;
    double acc[K];
 #pragma unroll
    for (int k = 0; k < K; k++) acc[k] = 0.0;
-   for (int c4 = lane; c4 * 4 < n; c4 += NKP_WAVE) {
-      const float4 v = m[c4];
-      const float mv[4] = { v.x, v.y, v.z, v.w };
+   for (int q0 = lane; q0 < nq; q0 += NKP_WAVE * 4) {
+      float4 v4[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-         if (c4 * 4 + j < n) {
+      for (int u = 0; u < 4; u++) {
+         const int q = q0 + u * NKP_WAVE;
+         v4[u] = q < nq ? m[q] : make_float4 (0.0f, 0.0f, 0.0f, 0.0f);
+      }
 #pragma unroll
-            for (int k = 0; k < K; k++) acc[k] += (double) mv[j] * x[(size_t) (c4 * 4 + j) * K + k];
-         }
+      for (int u = 0; u < 4; u++) {
+         const float mv[4] = { v4[u].x, v4[u].y, v4[u].z, v4[u].w };
+         const int c0 = (q0 + u * NKP_WAVE) * 4;
+#pragma unroll
+         for (int j = 0; j < 4; j++)
+            if (c0 + j < n) {
+#pragma unroll
+               for (int k = 0; k < K; k++) acc[k] += (double) mv[j] * x[(size_t) (c0 + j) * K + k];
+            }
+      }
    }
 #pragma unroll
    for (int k = 0; k < K; k++) {
