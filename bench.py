@@ -405,7 +405,7 @@ def main():
     if not distributed:
         for label, which, key, reps in (("csr_spmv_pipe_kernel<1, float> (smoother residual rows, fine level, one colour)", 3, "smoother_spmv_bytes", 100),
                                         ("colblock_apply_ldspack_kernel (water-column solves, fine level, one colour)", 4, "column_solve_bytes", 100),
-                                        ("whole V-cycle (all levels, ~150 launches)", 1, "cycle_bytes", 50)):
+                                        ("whole V-cycle (all levels, 88 launches)", 1, "cycle_bytes", 50)):
             ms = pre_ms if which == 1 else s.time_kernel(which, reps=reps)
             nbytes = s.get_int(key)
             if nbytes > 0 and ms > 0:
