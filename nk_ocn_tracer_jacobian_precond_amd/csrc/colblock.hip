@@ -239,21 +239,50 @@ void colblock_apply_kernel (const int *__restrict__ blk_start, int b_first, int 
 // x comes from TWO buffers like gs_fused_kernel's (rows < split from xa, the others from xb; new values to xout): columns
 // of one colour are coupled, so the sweep must not see its own updates (multilevel.hip ping-pongs the buffers).
 // Same products, same per-row summation order, same substitution as the two-kernel path => identical bits.
-#define GSW_UNROLL 32
+#define GSW_UNROLL 24
+#define GSW_CAP 1536          // entries of one water column staged per wave (LDS: 4 waves x 1536 x 8 bytes = 48 KB with f32 values)
+#define GSW_STAGE 8
 template <int P, int RPL, class VT, bool R32>
 __global__ __launch_bounds__ (CB_THREADS)
 void gs_wave_kernel (const int *__restrict__ rowptr, const int *__restrict__ colind, const VT *__restrict__ val,
                      const int *__restrict__ blk_start, int b_first, int b_end, int64_t n, const double *__restrict__ fac,
                      const double *__restrict__ xa, const double *__restrict__ xb, int split, const double *__restrict__ b, double *__restrict__ xout)
 {
+   // the (column, value) entries of the wave's water column -- one contiguous stretch of the CSR arrays -- are staged through LDS with
+   // coalesced loads; the row-per-lane reads they replace asked the L1 for every 128-byte line about 24 times (lanes 54 bytes
+   // apart, one instruction per entry of the row) and bounded the launch: 26 us per half sweep of the 1 degree level 2 (3416 waves)
+   extern __shared__ unsigned char gsw_lds[];
+   const int wv = threadIdx.x / NKP_WAVE;
+   int *sc = reinterpret_cast<int *> (gsw_lds) + wv * GSW_CAP;
+   VT *sv = reinterpret_cast<VT *> (gsw_lds + (size_t) CB_WAVES * GSW_CAP * sizeof (int)) + wv * GSW_CAP;
    const int blk = wave_block_id () + b_first;
-   if (blk >= b_end) return;
+   const bool act = blk < b_end;                    // (no early return: the whole workgroup meets at the barrier below)
    const int lane = threadIdx.x & (NKP_WAVE - 1);
-   const int r0 = blk_start[blk];
-   const int len = blk_start[blk + 1] - r0;
+   const int r0 = act ? blk_start[blk] : 0;
+   const int len = act ? blk_start[blk + 1] - r0 : 0;
 
    double y[RPL], xold[RPL], invd[RPL], L[RPL][P], U[RPL][P];
    int e0[RPL], rl[RPL];
+   // the column's stretch of entries (the lanes' own row pointers are requested below; these two come first)
+   const int e_begin = len > 0 ? rowptr[r0] : 0, e_total = len > 0 ? rowptr[r0 + len] - e_begin : 0;
+   const bool staged = e_total <= GSW_CAP;
+   if (staged) {
+      for (int k0 = 0; k0 < e_total; k0 += NKP_WAVE * GSW_STAGE) {
+         int tc[GSW_STAGE];
+         VT tv[GSW_STAGE];
+#pragma unroll
+         for (int u = 0; u < GSW_STAGE; u++) {
+            const int k = k0 + u * NKP_WAVE + lane;
+            tc[u] = k < e_total ? colind[e_begin + k] : 0;
+            tv[u] = k < e_total ? val[e_begin + k] : (VT) 0;
+         }
+#pragma unroll
+         for (int u = 0; u < GSW_STAGE; u++) {
+            const int k = k0 + u * NKP_WAVE + lane;
+            if (k < e_total) { sc[k] = tc[u]; sv[k] = tv[u]; }
+         }
+      }
+   }
 #pragma unroll
    for (int s = 0; s < RPL; s++) {
       const int li = s * NKP_WAVE + lane;
@@ -276,18 +305,29 @@ void gs_wave_kernel (const int *__restrict__ rowptr, const int *__restrict__ col
          }
       }
    }
-   // residual of this lane's row(s): entries in stored order, GSW_UNROLL of them requested together (one round trip for the (column, value) pairs, one for the gathered x, whatever the row length up to 32)
+   __syncthreads ();
+   // residual of this lane's row(s): entries in stored order, GSW_UNROLL of them requested together (from LDS, or one round trip for the (column, value) pairs of a column too long to stage; then one for the gathered x)
 #pragma unroll
    for (int s = 0; s < RPL; s++) {
       double acc = 0.0;
       for (int k0 = 0; __any (k0 < rl[s]); k0 += GSW_UNROLL) {
          int cc[GSW_UNROLL];
          VT vv[GSW_UNROLL];
+         if (staged) {
+            const int off = e0[s] - e_begin + k0;
 #pragma unroll
-         for (int u = 0; u < GSW_UNROLL; u++) {
-            const bool ok = k0 + u < rl[s];
-            cc[u] = ok ? colind[e0[s] + k0 + u] : 0;
-            vv[u] = ok ? val[e0[s] + k0 + u] : (VT) 0;
+            for (int u = 0; u < GSW_UNROLL; u++) {
+               const bool ok = k0 + u < rl[s];
+               cc[u] = ok ? sc[off + u] : 0;
+               vv[u] = ok ? sv[off + u] : (VT) 0;
+            }
+         } else {
+#pragma unroll
+            for (int u = 0; u < GSW_UNROLL; u++) {
+               const bool ok = k0 + u < rl[s];
+               cc[u] = ok ? colind[e0[s] + k0 + u] : 0;
+               vv[u] = ok ? val[e0[s] + k0 + u] : (VT) 0;
+            }
          }
          double xv[GSW_UNROLL];
 #pragma unroll
@@ -400,8 +440,11 @@ void launch_gs_wave (const CsrDev &L, const ColBlocksDev &B, int b0, int b1, con
    if (b1 <= b0) return;
    const int rpl = B.max_len <= NKP_WAVE ? 1 : 2;
    const dim3 grid = cb_grid (b1 - b0);
-#define GSW_GO(PP, RR, VT_, R32_, VAL_) hipLaunchKernelGGL ((gs_wave_kernel<PP, RR, VT_, R32_>), grid, dim3 (CB_THREADS), 0, st, L.rowptr, L.colind, VAL_, \
-                                                              B.blk_start, b0, b1, B.n, B.fac, xa, xb, split, b, xout)
+#define GSW_GO(PP, RR, VT_, R32_, VAL_) do { const size_t lds_ = (size_t) CB_WAVES * GSW_CAP * (sizeof (int) + sizeof (VT_));                              \
+                                             static bool opted_ = false;                                                                                        \
+                                             if (lds_ > 48 * 1024 && !opted_) { (void) hipFuncSetAttribute ((const void *) gs_wave_kernel<PP, RR, VT_, R32_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_); opted_ = true; } \
+                                             hipLaunchKernelGGL ((gs_wave_kernel<PP, RR, VT_, R32_>), grid, dim3 (CB_THREADS), lds_, st, L.rowptr, L.colind, VAL_, \
+                                                                 B.blk_start, b0, b1, B.n, B.fac, xa, xb, split, b, xout); } while (0)
 #define GSW_PR(PP, RR) do { if (L.valf) { if (r32) GSW_GO (PP, RR, float, true, L.valf); else GSW_GO (PP, RR, float, false, L.valf); } \
                             else { if (r32) GSW_GO (PP, RR, double, true, L.val); else GSW_GO (PP, RR, double, false, L.val); } } while (0)
    if (B.P == 1) { if (rpl == 1) GSW_PR (1, 1); else GSW_PR (1, 2); }
