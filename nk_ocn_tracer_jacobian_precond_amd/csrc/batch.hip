@@ -523,18 +523,53 @@ void colblock_apply_wave_batch_kernel (const int *__restrict__ blk_start, int b_
 
 // gs_wave_kernel (colblock.hip) on K columns: residual of the column's rows, band solve, xout = x + z in one launch
 #define BGS_UNROLL 16
+#define BGS_CAP 1536
 template <int P, int RPL, class VT, bool R32, int K>
 __global__ __launch_bounds__ (BT_THREADS)
 void gs_wave_batch_kernel (const int *__restrict__ rowptr, const int *__restrict__ colind, const VT *__restrict__ val, const int *__restrict__ blk_start,
                            int b_first, int b_end, int64_t n, const double *__restrict__ fac, const double *__restrict__ xa, const double *__restrict__ xb,
-                           int split, const double *__restrict__ b, double *__restrict__ xout)
+                           int split, const double *__restrict__ b, double *__restrict__ xout, const int4 *__restrict__ desc)
 {
+   // the column's entries through LDS with coalesced loads, like gs_wave_kernel (colblock.hip)
+   extern __shared__ unsigned char bgs_lds[];
+   const int wv = threadIdx.x / NKP_WAVE;
+   int *sc = reinterpret_cast<int *> (bgs_lds) + wv * BGS_CAP;
+   VT *sv = reinterpret_cast<VT *> (bgs_lds + (size_t) BT_WAVES * BGS_CAP * sizeof (int)) + wv * BGS_CAP;
    const int blk = __builtin_amdgcn_readfirstlane ((int) ((blockIdx.x * BT_THREADS + threadIdx.x) / NKP_WAVE)) + b_first;
-   if (blk >= b_end) return;
+   const bool act = blk < b_end;
    const int lane = threadIdx.x & (NKP_WAVE - 1);
-   const int r0 = blk_start[blk], len = blk_start[blk + 1] - r0;
+   int4 d4 = make_int4 (0, 0, 0, 0);
+   if (act) {
+      if (desc) d4 = desc[blk];
+      else {
+         d4.x = blk_start[blk];
+         d4.y = blk_start[blk + 1] - d4.x;
+         d4.z = d4.y > 0 ? rowptr[d4.x] : 0;
+         d4.w = d4.y > 0 ? rowptr[d4.x + d4.y] - d4.z : 0;
+      }
+   }
+   const int r0 = d4.x, len = d4.y;
    double y[RPL][K], xold[RPL][K], invd[RPL], L[RPL][P], U[RPL][P];
    int e0[RPL], rl[RPL];
+   const int e_begin = d4.z, e_total = d4.w;
+   const bool staged = e_total <= BGS_CAP;
+   if (staged) {
+      for (int k0 = 0; k0 < e_total; k0 += NKP_WAVE * 8) {
+         int tc[8];
+         VT tv[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            const int k = k0 + u * NKP_WAVE + lane;
+            tc[u] = k < e_total ? colind[e_begin + k] : 0;
+            tv[u] = k < e_total ? val[e_begin + k] : (VT) 0;
+         }
+#pragma unroll
+         for (int u = 0; u < 8; u++) {
+            const int k = k0 + u * NKP_WAVE + lane;
+            if (k < e_total) { sc[k] = tc[u]; sv[k] = tv[u]; }
+         }
+      }
+   }
    wave_load_factors<P, RPL, R32> (n, r0, len, lane, fac, invd, L, U);
 #pragma unroll
    for (int s = 0; s < RPL; s++) {
@@ -551,6 +586,7 @@ void gs_wave_batch_kernel (const int *__restrict__ rowptr, const int *__restrict
          for (int q = 0; q < K; q++) { y[s][q] = b[r * K + q]; xold[s][q] = xo[r * K + q]; }
       }
    }
+   __syncthreads ();
 #pragma unroll
    for (int s = 0; s < RPL; s++) {
       double acc[K];
@@ -559,11 +595,21 @@ void gs_wave_batch_kernel (const int *__restrict__ rowptr, const int *__restrict
       for (int k0 = 0; __any (k0 < rl[s]); k0 += BGS_UNROLL) {
          int cc[BGS_UNROLL];
          VT vv[BGS_UNROLL];
+         if (staged) {
+            const int off = e0[s] - e_begin + k0;
 #pragma unroll
-         for (int u = 0; u < BGS_UNROLL; u++) {
-            const bool ok = k0 + u < rl[s];
-            cc[u] = ok ? colind[e0[s] + k0 + u] : 0;
-            vv[u] = ok ? val[e0[s] + k0 + u] : (VT) 0;
+            for (int u = 0; u < BGS_UNROLL; u++) {
+               const bool ok = k0 + u < rl[s];
+               cc[u] = ok ? sc[off + u] : 0;
+               vv[u] = ok ? sv[off + u] : (VT) 0;
+            }
+         } else {
+#pragma unroll
+            for (int u = 0; u < BGS_UNROLL; u++) {
+               const bool ok = k0 + u < rl[s];
+               cc[u] = ok ? colind[e0[s] + k0 + u] : 0;
+               vv[u] = ok ? val[e0[s] + k0 + u] : (VT) 0;
+            }
          }
          double2 xg[K / 2][BGS_UNROLL];
 #pragma unroll
@@ -618,8 +664,11 @@ void launch_gs_wave_batch (int K, const CsrDev &L, const ColBlocksDev &B, int b0
 {
    if (b1 <= b0) return;
    const int rpl = B.max_len <= NKP_WAVE ? 1 : 2;
-#define GW_GO(PP, RR, VT_, R32_, K_, VAL_) hipLaunchKernelGGL ((gs_wave_batch_kernel<PP, RR, VT_, R32_, K_>), bt_wave_grid (b1 - b0), dim3 (BT_THREADS), 0, st, \
-                                                                L.rowptr, L.colind, VAL_, B.blk_start, b0, b1, B.n, B.fac, xa, xb, split, b, xout)
+#define GW_GO(PP, RR, VT_, R32_, K_, VAL_) do { const size_t lds_ = (size_t) BT_WAVES * BGS_CAP * (sizeof (int) + sizeof (VT_));                                   \
+                                                static bool opted_ = false;                                                                                             \
+                                                if (lds_ > 48 * 1024 && !opted_) { (void) hipFuncSetAttribute ((const void *) gs_wave_batch_kernel<PP, RR, VT_, R32_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_); opted_ = true; } \
+                                                hipLaunchKernelGGL ((gs_wave_batch_kernel<PP, RR, VT_, R32_, K_>), bt_wave_grid (b1 - b0), dim3 (BT_THREADS), lds_, st, \
+                                                                    L.rowptr, L.colind, VAL_, B.blk_start, b0, b1, B.n, B.fac, xa, xb, split, b, xout, reinterpret_cast<const int4 *> (B.wave_desc)); } while (0)
 #define GW_K(PP, RR, VT_, R32_, VAL_) do { if (K == 2) GW_GO (PP, RR, VT_, R32_, 2, VAL_); else GW_GO (PP, RR, VT_, R32_, 4, VAL_); } while (0)
 #define GW_PR(PP, RR) do { if (L.valf) { if (r32) GW_K (PP, RR, float, true, L.valf); else GW_K (PP, RR, float, false, L.valf); } \
                            else { if (r32) GW_K (PP, RR, double, true, L.val); else GW_K (PP, RR, double, false, L.val); } } while (0)

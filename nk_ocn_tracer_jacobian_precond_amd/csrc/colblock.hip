@@ -246,7 +246,8 @@ template <int P, int RPL, class VT, bool R32>
 __global__ __launch_bounds__ (CB_THREADS)
 void gs_wave_kernel (const int *__restrict__ rowptr, const int *__restrict__ colind, const VT *__restrict__ val,
                      const int *__restrict__ blk_start, int b_first, int b_end, int64_t n, const double *__restrict__ fac,
-                     const double *__restrict__ xa, const double *__restrict__ xb, int split, const double *__restrict__ b, double *__restrict__ xout)
+                     const double *__restrict__ xa, const double *__restrict__ xb, int split, const double *__restrict__ b, double *__restrict__ xout,
+                     const int4 *__restrict__ desc)
 {
    // the (column, value) entries of the wave's water column -- one contiguous stretch of the CSR arrays -- are staged through LDS with
    // coalesced loads; the row-per-lane reads they replace asked the L1 for every 128-byte line about 24 times (lanes 54 bytes
@@ -258,13 +259,22 @@ void gs_wave_kernel (const int *__restrict__ rowptr, const int *__restrict__ col
    const int blk = wave_block_id () + b_first;
    const bool act = blk < b_end;                    // (no early return: the whole workgroup meets at the barrier below)
    const int lane = threadIdx.x & (NKP_WAVE - 1);
-   const int r0 = act ? blk_start[blk] : 0;
-   const int len = act ? blk_start[blk + 1] - r0 : 0;
+   // {first row, rows, first entry, entries} of the column in one 16-byte load (desc: built at setup), else through blk_start and rowptr
+   int4 d4 = make_int4 (0, 0, 0, 0);
+   if (act) {
+      if (desc) d4 = desc[blk];
+      else {
+         d4.x = blk_start[blk];
+         d4.y = blk_start[blk + 1] - d4.x;
+         d4.z = d4.y > 0 ? rowptr[d4.x] : 0;
+         d4.w = d4.y > 0 ? rowptr[d4.x + d4.y] - d4.z : 0;
+      }
+   }
+   const int r0 = d4.x, len = d4.y;
 
    double y[RPL], xold[RPL], invd[RPL], L[RPL][P], U[RPL][P];
    int e0[RPL], rl[RPL];
-   // the column's stretch of entries (the lanes' own row pointers are requested below; these two come first)
-   const int e_begin = len > 0 ? rowptr[r0] : 0, e_total = len > 0 ? rowptr[r0 + len] - e_begin : 0;
+   const int e_begin = d4.z, e_total = d4.w;
    const bool staged = e_total <= GSW_CAP;
    if (staged) {
       for (int k0 = 0; k0 < e_total; k0 += NKP_WAVE * GSW_STAGE) {
@@ -432,6 +442,22 @@ void launch_colblock_apply_range_r32 (const ColBlocksDev &B, int b0, int b1, con
 #undef R32_GO
 }
 
+__global__ __launch_bounds__ (CB_THREADS)
+void wave_desc_kernel (const int *__restrict__ rowptr, const int *__restrict__ blk_start, int nblk, int4 *__restrict__ desc)
+{
+   const int b = blockIdx.x * CB_THREADS + threadIdx.x;
+   if (b >= nblk) return;
+   const int r0 = blk_start[b], len = blk_start[b + 1] - r0;
+   const int e0 = len > 0 ? rowptr[r0] : 0;
+   desc[b] = make_int4 (r0, len, e0, len > 0 ? rowptr[r0 + len] - e0 : 0);
+}
+
+void launch_build_wave_desc (const CsrDev &L, ColBlocksDev &B, hipStream_t st)
+{
+   if (B.nblk > 0 && B.wave_desc)
+      hipLaunchKernelGGL (wave_desc_kernel, dim3 ((B.nblk + CB_THREADS - 1) / CB_THREADS), dim3 (CB_THREADS), 0, st, L.rowptr, B.blk_start, B.nblk, reinterpret_cast<int4 *> (B.wave_desc));
+}
+
 // blocks [b0, b1) of one colour: xout_rows = x_rows + M^-1 (b - L x)_rows in one launch (gs_wave_kernel); r32: factors rounded
 // to f32 on load (the f32 storage mode of the cycle).  The level operator is read through L.valf when it has an f32 copy.
 void launch_gs_wave (const CsrDev &L, const ColBlocksDev &B, int b0, int b1, const double *xa, const double *xb, int split, const double *b, double *xout,
@@ -444,7 +470,7 @@ void launch_gs_wave (const CsrDev &L, const ColBlocksDev &B, int b0, int b1, con
                                              static bool opted_ = false;                                                                                        \
                                              if (lds_ > 48 * 1024 && !opted_) { (void) hipFuncSetAttribute ((const void *) gs_wave_kernel<PP, RR, VT_, R32_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_); opted_ = true; } \
                                              hipLaunchKernelGGL ((gs_wave_kernel<PP, RR, VT_, R32_>), grid, dim3 (CB_THREADS), lds_, st, L.rowptr, L.colind, VAL_, \
-                                                                 B.blk_start, b0, b1, B.n, B.fac, xa, xb, split, b, xout); } while (0)
+                                                                 B.blk_start, b0, b1, B.n, B.fac, xa, xb, split, b, xout, reinterpret_cast<const int4 *> (B.wave_desc)); } while (0)
 #define GSW_PR(PP, RR) do { if (L.valf) { if (r32) GSW_GO (PP, RR, float, true, L.valf); else GSW_GO (PP, RR, float, false, L.valf); } \
                             else { if (r32) GSW_GO (PP, RR, double, true, L.val); else GSW_GO (PP, RR, double, false, L.val); } } while (0)
    if (B.P == 1) { if (rpl == 1) GSW_PR (1, 1); else GSW_PR (1, 2); }

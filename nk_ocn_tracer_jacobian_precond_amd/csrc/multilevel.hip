@@ -1014,6 +1014,10 @@ int finish_level_columns (MlHierarchy &H, MlLevel &V, int l, const std::vector<i
       V.wave_columns = ncol <= H.tune->col_wave_max && V.B.dropped == 0;
       // ... and their half sweeps are one launch each (residual of the column's rows + its band solve, gs_wave_kernel)
       V.wave_fused = V.wave_columns && (H.tune->ml_wave_fused == 1 || (H.tune->ml_wave_fused > 1 && ncol <= H.tune->ml_wave_fused));
+      if (V.wave_fused) {
+         if (!upload (&V.B.wave_desc, (const int *) nullptr, (size_t) 4 * (size_t) ncol, &H.device_bytes)) ML_FAIL (-2, "multilevel setup: device allocation failed");
+         launch_build_wave_desc (V.L, V.B, st);
+      }
       // the block-per-group fused kernel serves matching storage only (f32 operator with f32 factors, or f64 with f64)
       if (V.B.gs_ok && !((V.B.fac_tf && V.L.valf) || (V.B.fac_t && !V.L.valf))) V.B.gs_ok = 0;
       T.lay += secs_since (t_lay0);
@@ -1485,7 +1489,7 @@ int ml_setup (MlHierarchy &H, int64_t n, const int *rowptr, const int *colind, c
 void ml_free (MlHierarchy &H)
 {
    for (MlLevel &V : H.lev) {
-      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.valf, V.B.fac_tf, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.grp_row0, V.B.col_slot, V.B.fac_t, V.B.gs_rb_ptr, V.B.gs_rb, V.cmap, V.rptr, V.ridx, V.x, V.x2, V.b, V.r, V.bx, V.bx2, V.bb, V.br };
+      void *ptrs[] = { V.L.rowptr, V.L.colind, V.L.val, V.L.valf, V.B.fac_tf, V.L.rowblk, V.L.codes, V.L.dict, V.L.dict_ptr, V.B.blk_start, V.B.fac, V.B.grp_b0, V.B.grp_nb, V.B.grp_maxlen, V.B.grp_base, V.B.grp_row0, V.B.col_slot, V.B.fac_t, V.B.gs_rb_ptr, V.B.gs_rb, V.B.wave_desc, V.cmap, V.rptr, V.ridx, V.x, V.x2, V.b, V.r, V.bx, V.bx2, V.bb, V.br };
       for (void *p : ptrs)
          if (p) (void) hipFree (p);
    }

@@ -86,6 +86,7 @@ struct ColBlocksDev {
    int gs_lds_bytes = 0;
    int *gs_rb_ptr = nullptr;   // [ngrp+1] first row-block boundary of the group
    int *gs_rb = nullptr;       // row-block boundaries (rows), groups back to back
+   int *wave_desc = nullptr;   // levels run by gs_wave_kernel: per column {first row, rows, first entry, entries} -- one load instead of two dependent ones
    const nkp_tuning *tune = nullptr;   // kernel selection knobs of the owning solver (NULL: built-in defaults)
 };
 
@@ -116,6 +117,7 @@ void launch_colblock_apply_range (const ColBlocksDev &B, int b0, int b1, const d
 void launch_colblock_apply_range_r32 (const ColBlocksDev &B, int b0, int b1, const double *r, double *z, int accumulate, hipStream_t st);
 // blocks [b0, b1) of one colour in ONE launch, one column per wave: xout_rows = x_rows + M_blk^-1 (b - L x)_rows, x taken from
 // xa (rows < split) and xb (the others); r32 as above
+void launch_build_wave_desc (const CsrDev &L, ColBlocksDev &B, hipStream_t st);   // fills B.wave_desc (allocated by the caller: 4 ints per column)
 void launch_gs_wave (const CsrDev &L, const ColBlocksDev &B, int b0, int b1, const double *xa, const double *xb, int split, const double *b, double *xout,
                      int r32, hipStream_t st);
 
