@@ -1359,7 +1359,8 @@ int colblock_build_lane_layout (ColBlocksDev &B, const int *h_blk_start, const i
       // the streamed kernel on the largest levels), =0 switches it off.
       const int lr = T.col_ldsres;
       const int ncols = ranges[nranges] - ranges[0];
-      const int min_long = env_min ? min_cols : 8000, min_short = env_min ? min_cols : 20000;
+      int min_long = env_min ? min_cols : 8000, min_short = env_min ? min_cols : 20000;
+      if (T.col_ldsres_min > 0) min_long = min_short = T.col_ldsres_min;     // A/B: the LDS-resident kernels from that many columns only
       B.ldsres = lr > 0 && on && B.max_len <= 128 && ((B.max_len > 64 && ncols >= min_long) || (lr == 2 && ncols >= min_short));
       if (B.ldsres) { B.stream = 0; gw = 32; }
       // 2 = factors packed four steps to a 16-byte load (colblock_apply_ldspack_kernel): f32 storage, at most 5 chunks of 16
