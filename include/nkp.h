@@ -114,7 +114,9 @@ typedef struct nkp_tuning {
    int spmv_wgs;             /* NKP_SPMV_WGS (256): workgroups per CU at most */
    /* ---- Krylov / distributed flavour / setup */
    int rhs_batch;            /* NKP_RHS_BATCH (1): several right-hand sides of one call share the sweeps over the matrix and the
-                                hierarchy (nkp_solve_batch_device; same bits per column); 0 = one at a time */
+                                hierarchy (nkp_solve_batch_device; same bits per column); 0 = one at a time, 1 or 4 = groups of up to
+                                four, 2 = pairs, 8 = groups of up to eight (measured at 1 degree: no better per solve than four -- with
+                                four vectors interleaved the vectors, not the matrix, are most of every kernel's bytes) */
    int precond_steps;        /* NKP_PRECOND_STEPS (0 = leave nkp_options.precond_steps) */
    int equil;                /* NKP_EQUIL (-1 = leave nkp_options.equil) */
    int dist_overlap;         /* NKP_DIST_OVERLAP (1): halo exchange behind the interior rows */

@@ -18,8 +18,8 @@ static inline int bt_grid (int64_t n) { int64_t g = (n + BT_THREADS - 1) / BT_TH
 
 // ---------------------------------------------------------------- interleave / de-interleave
 // X[i * K + k] = src_k[i]; systems without a vector (src_k == NULL) contribute zeros
-struct BatchPtrs { const double *p[4]; };
-struct BatchOutPtrs { double *p[4]; };
+struct BatchPtrs { const double *p[NKP_BATCH_MAX]; };
+struct BatchOutPtrs { double *p[NKP_BATCH_MAX]; };
 
 template <int K>
 __global__ __launch_bounds__ (BT_THREADS)
@@ -47,17 +47,19 @@ void deinterleave_kernel (const double *__restrict__ X, BatchOutPtrs dst, int64_
 void launch_interleave (int K, const double *const *src, double *X, int64_t n, hipStream_t st)
 {
    BatchPtrs P;
-   for (int k = 0; k < 4; k++) P.p[k] = k < K ? src[k] : nullptr;
+   for (int k = 0; k < NKP_BATCH_MAX; k++) P.p[k] = k < K ? src[k] : nullptr;
    if (K == 2) hipLaunchKernelGGL (interleave_kernel<2>, dim3 (bt_grid (n)), dim3 (BT_THREADS), 0, st, P, X, n);
-   else hipLaunchKernelGGL (interleave_kernel<4>, dim3 (bt_grid (n)), dim3 (BT_THREADS), 0, st, P, X, n);
+   else if (K == 4) hipLaunchKernelGGL (interleave_kernel<4>, dim3 (bt_grid (n)), dim3 (BT_THREADS), 0, st, P, X, n);
+   else hipLaunchKernelGGL (interleave_kernel<8>, dim3 (bt_grid (n)), dim3 (BT_THREADS), 0, st, P, X, n);
 }
 
 void launch_deinterleave (int K, const double *X, double *const *dst, int64_t n, hipStream_t st)
 {
    BatchOutPtrs P;
-   for (int k = 0; k < 4; k++) P.p[k] = k < K ? dst[k] : nullptr;
+   for (int k = 0; k < NKP_BATCH_MAX; k++) P.p[k] = k < K ? dst[k] : nullptr;
    if (K == 2) hipLaunchKernelGGL (deinterleave_kernel<2>, dim3 (bt_grid (n)), dim3 (BT_THREADS), 0, st, X, P, n);
-   else hipLaunchKernelGGL (deinterleave_kernel<4>, dim3 (bt_grid (n)), dim3 (BT_THREADS), 0, st, X, P, n);
+   else if (K == 4) hipLaunchKernelGGL (deinterleave_kernel<4>, dim3 (bt_grid (n)), dim3 (BT_THREADS), 0, st, X, P, n);
+   else hipLaunchKernelGGL (deinterleave_kernel<8>, dim3 (bt_grid (n)), dim3 (BT_THREADS), 0, st, X, P, n);
 }
 
 // ---------------------------------------------------------------- CSR SpMV, K columns
@@ -252,7 +254,8 @@ void launch_csr_spmv_batch (int K, const CsrDev &A, int rb0, int rb1, const doub
    const nkp_tuning &T = A.tune ? *A.tune : nkp_builtin_tuning ();
 #define BSPMV(KERNEL_, MODE_, VT_, K_, VAL_) hipLaunchKernelGGL ((KERNEL_<MODE_, VT_, K_>), dim3 (per_xcd * 8), dim3 (BT_THREADS), 0, st, \
                                                                  A.rowblk, rb0, cnt, per_xcd, A.rowptr, A.colind, VAL_, x, y, b)
-#define BSPMV_K(MODE_, VT_, VAL_) do { if (T.batch_spmv_rows) { if (K == 2) BSPMV (csr_spmv_batch_rows_kernel, MODE_, VT_, 2, VAL_); else BSPMV (csr_spmv_batch_rows_kernel, MODE_, VT_, 4, VAL_); } \
+#define BSPMV_K(MODE_, VT_, VAL_) do { if (K == 8) BSPMV (csr_spmv_batch_rows_kernel, MODE_, VT_, 8, VAL_);      /* (the products-in-LDS variant stops at four) */ \
+                                       else if (T.batch_spmv_rows) { if (K == 2) BSPMV (csr_spmv_batch_rows_kernel, MODE_, VT_, 2, VAL_); else BSPMV (csr_spmv_batch_rows_kernel, MODE_, VT_, 4, VAL_); } \
                                        else { if (K == 2) BSPMV (csr_spmv_batch_kernel, MODE_, VT_, 2, VAL_); else BSPMV (csr_spmv_batch_kernel, MODE_, VT_, 4, VAL_); } } while (0)
    if (A.valf) { if (mode == 0) BSPMV_K (0, float, A.valf); else BSPMV_K (1, float, A.valf); }
    else { if (mode == 0) BSPMV_K (0, double, A.val); else BSPMV_K (1, double, A.val); }
@@ -267,11 +270,11 @@ void launch_csr_spmv_batch_split (int K, const CsrDev &A, const double *x, doubl
    if (cnt <= 0) return;
    const int per_xcd = (cnt + 7) / 8;
    BatchOutPtrs P;
-   for (int k = 0; k < 4; k++) P.p[k] = k < K ? dst[k] : nullptr;
+   for (int k = 0; k < NKP_BATCH_MAX; k++) P.p[k] = k < K ? dst[k] : nullptr;
 #define BSPLIT(VT_, K_, VAL_) hipLaunchKernelGGL ((csr_spmv_batch_rows_kernel<0, VT_, K_, true>), dim3 (per_xcd * 8), dim3 (BT_THREADS), 0, st, \
                                                   A.rowblk, 0, cnt, per_xcd, A.rowptr, A.colind, VAL_, x, (double *) nullptr, (const double *) nullptr, P)
-   if (A.valf) { if (K == 2) BSPLIT (float, 2, A.valf); else BSPLIT (float, 4, A.valf); }
-   else { if (K == 2) BSPLIT (double, 2, A.val); else BSPLIT (double, 4, A.val); }
+   if (A.valf) { if (K == 2) BSPLIT (float, 2, A.valf); else if (K == 4) BSPLIT (float, 4, A.valf); else BSPLIT (float, 8, A.valf); }
+   else { if (K == 2) BSPLIT (double, 2, A.val); else if (K == 4) BSPLIT (double, 4, A.val); else BSPLIT (double, 8, A.val); }
 #undef BSPLIT
 }
 
@@ -368,7 +371,8 @@ void dense_matvec_batch_kernel (const double *__restrict__ M, const double *__re
 }
 
 #define BT_K(KERNEL, GRID, ...) do { if (K == 2) hipLaunchKernelGGL ((KERNEL<2>), GRID, dim3 (BT_THREADS), 0, st, __VA_ARGS__); \
-                                     else hipLaunchKernelGGL ((KERNEL<4>), GRID, dim3 (BT_THREADS), 0, st, __VA_ARGS__); } while (0)
+                                     else if (K == 4) hipLaunchKernelGGL ((KERNEL<4>), GRID, dim3 (BT_THREADS), 0, st, __VA_ARGS__); \
+                                     else hipLaunchKernelGGL ((KERNEL<8>), GRID, dim3 (BT_THREADS), 0, st, __VA_ARGS__); } while (0)
 
 void launch_restrict_sum_batch (int K, const int *rptr, const int *ridx, const double *fine, double *coarse, int64_t nc, hipStream_t st)
 {
@@ -389,13 +393,13 @@ void launch_scatter_batch (int K, const int *perm, const double *in, double *out
 void launch_gather_interleave (int K, const int *perm, const double *const *src, double *out, int64_t n, hipStream_t st)
 {
    BatchPtrs P;
-   for (int k = 0; k < 4; k++) P.p[k] = k < K ? src[k] : nullptr;
+   for (int k = 0; k < NKP_BATCH_MAX; k++) P.p[k] = k < K ? src[k] : nullptr;
    if (n > 0) BT_K (gather_interleave_kernel, dim3 (bt_grid (n)), perm, P, out, n);
 }
 void launch_scatter_split (int K, const int *perm, const double *in, double *z, double *const *dst, int64_t n, hipStream_t st)
 {
    BatchOutPtrs P;
-   for (int k = 0; k < 4; k++) P.p[k] = k < K ? dst[k] : nullptr;
+   for (int k = 0; k < NKP_BATCH_MAX; k++) P.p[k] = k < K ? dst[k] : nullptr;
    if (n > 0) BT_K (scatter_split_kernel, dim3 (bt_grid (n)), perm, in, z, P, n);
 }
 void launch_dense_matvec_batch (int K, const double *Minv, const double *x, double *y, int n, hipStream_t st)
@@ -522,7 +526,7 @@ void colblock_apply_wave_batch_kernel (const int *__restrict__ blk_start, int b_
 }
 
 // gs_wave_kernel (colblock.hip) on K columns: residual of the column's rows, band solve, xout = x + z in one launch
-#define BGS_UNROLL 16
+#define BGS_UNROLL (K >= 8 ? 8 : 16)          // entries (x K values each) requested together
 #define BGS_CAP 1536
 template <int P, int RPL, class VT, bool R32, int K>
 __global__ __launch_bounds__ (BT_THREADS)
@@ -649,7 +653,7 @@ void launch_colblock_apply_wave_batch (int K, const ColBlocksDev &B, int b0, int
    const int rpl = B.max_len <= NKP_WAVE ? 1 : 2;
 #define CW_GO(PP, RR, R32_, K_) hipLaunchKernelGGL ((colblock_apply_wave_batch_kernel<PP, RR, R32_, K_>), bt_wave_grid (b1 - b0), dim3 (BT_THREADS), 0, st, \
                                                      B.blk_start, b0, b1, B.n, B.fac, r, z, accumulate)
-#define CW_K(PP, RR, R32_) do { if (K == 2) CW_GO (PP, RR, R32_, 2); else CW_GO (PP, RR, R32_, 4); } while (0)
+#define CW_K(PP, RR, R32_) do { if (K == 2) CW_GO (PP, RR, R32_, 2); else if (K == 4) CW_GO (PP, RR, R32_, 4); else CW_GO (PP, RR, R32_, 8); } while (0)
 #define CW_R(PP, RR) do { if (r32) CW_K (PP, RR, true); else CW_K (PP, RR, false); } while (0)
    if (B.P == 1) { if (rpl == 1) CW_R (1, 1); else CW_R (1, 2); }
    else if (B.P == 2) { if (rpl == 1) CW_R (2, 1); else CW_R (2, 2); }
@@ -669,7 +673,7 @@ void launch_gs_wave_batch (int K, const CsrDev &L, const ColBlocksDev &B, int b0
                                                 if (lds_ > 48 * 1024 && !opted_) { (void) hipFuncSetAttribute ((const void *) gs_wave_batch_kernel<PP, RR, VT_, R32_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_); opted_ = true; } \
                                                 hipLaunchKernelGGL ((gs_wave_batch_kernel<PP, RR, VT_, R32_, K_>), bt_wave_grid (b1 - b0), dim3 (BT_THREADS), lds_, st, \
                                                                     L.rowptr, L.colind, VAL_, B.blk_start, b0, b1, B.n, B.fac, xa, xb, split, b, xout, reinterpret_cast<const int4 *> (B.wave_desc)); } while (0)
-#define GW_K(PP, RR, VT_, R32_, VAL_) do { if (K == 2) GW_GO (PP, RR, VT_, R32_, 2, VAL_); else GW_GO (PP, RR, VT_, R32_, 4, VAL_); } while (0)
+#define GW_K(PP, RR, VT_, R32_, VAL_) do { if (K == 2) GW_GO (PP, RR, VT_, R32_, 2, VAL_); else if (K == 4) GW_GO (PP, RR, VT_, R32_, 4, VAL_); else GW_GO (PP, RR, VT_, R32_, 8, VAL_); } while (0)
 #define GW_PR(PP, RR) do { if (L.valf) { if (r32) GW_K (PP, RR, float, true, L.valf); else GW_K (PP, RR, float, false, L.valf); } \
                            else { if (r32) GW_K (PP, RR, double, true, L.val); else GW_K (PP, RR, double, false, L.val); } } while (0)
    if (B.P == 1) { if (rpl == 1) GW_PR (1, 1); else GW_PR (1, 2); }

@@ -1927,10 +1927,12 @@ template <int P, int NCH>
 __global__ __launch_bounds__ (NKP_WAVE, 2)
 void colblock_apply_ldspack4_kernel (const int *__restrict__ grp_maxlen, const long long *__restrict__ grp_base, int g_first,
                                      const float *__restrict__ fac_t, const double *__restrict__ rhs, double *__restrict__ z, int accumulate,
-                                     const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp)
+                                     const int *__restrict__ grp_row0, const int *__restrict__ col_slot, int ngrp, int K /* vectors interleaved */, int k0 /* first of this launch's four */)
 {
    extern __shared__ double lds[];
-   constexpr int gw = 32, hw = 16, K = 4, CH = 16, STRIDE = NCH * CH + 1;
+   constexpr int gw = 32, hw = 16, CH = 16, STRIDE = NCH * CH + 1;
+   rhs += k0;
+   z += k0;
    constexpr LdspSchedule<NCH, P * CH, (P + 1) * CH> S;
    const int g = (int) (blockIdx.x >> 1) + g_first, half = blockIdx.x & 1;
    const int lane = threadIdx.x;
@@ -2047,16 +2049,18 @@ int launch_colblock_apply_lanes_batch (int K, const ColBlocksDev &B, int g0, int
    if (g1 <= g0) return 0;
    const int nch = B.max_len <= 64 ? 4 : 5;
    const size_t lds = (size_t) 64 * (size_t) (nch * NKP_LDSRES_CH + 1) * sizeof (double);
-   if (K == 4) {
-      // one launch for the four systems, two waves (16 columns each) per group
+   if (K % 4 == 0) {
+      // one launch per four systems, two waves (16 columns each) per group
+      for (int k0 = 0; k0 < K; k0 += 4) {
 #define LDSP4_LAUNCH(PP) do { if (nch == 4) hipLaunchKernelGGL ((colblock_apply_ldspack4_kernel<PP, 4>), dim3 (2 * (g1 - g0)), dim3 (NKP_WAVE), lds, st, B.grp_maxlen, B.grp_base, g0, \
-                                                                 B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp);                                                \
+                                                                 B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp, K, k0);                                         \
                               else hipLaunchKernelGGL ((colblock_apply_ldspack4_kernel<PP, 5>), dim3 (2 * (g1 - g0)), dim3 (NKP_WAVE), lds, st, B.grp_maxlen, B.grp_base, g0,  \
-                                                       B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp); } while (0)
-      if (B.P == 1) LDSP4_LAUNCH (1);
-      else if (B.P == 2) LDSP4_LAUNCH (2);
-      else LDSP4_LAUNCH (4);
+                                                       B.fac_tf, r, z, accumulate, B.grp_row0, B.col_slot, B.ngrp, K, k0); } while (0)
+         if (B.P == 1) LDSP4_LAUNCH (1);
+         else if (B.P == 2) LDSP4_LAUNCH (2);
+         else LDSP4_LAUNCH (4);
 #undef LDSP4_LAUNCH
+      }
       return 0;
    }
    for (int k0 = 0; k0 < K; k0 += 2) {

@@ -315,5 +315,6 @@ void launch_dense_matvec_f32_batch (int K, const float *Minv, int ld, const doub
 {
    if (n <= 0) return;
    if (K == 2) hipLaunchKernelGGL ((dense_matvec_f32_batch_kernel<2>), dim3 ((n + 3) / 4), dim3 (256), 0, st, Minv, ld, x, y, n);
-   else hipLaunchKernelGGL ((dense_matvec_f32_batch_kernel<4>), dim3 ((n + 3) / 4), dim3 (256), 0, st, Minv, ld, x, y, n);
+   else if (K == 4) hipLaunchKernelGGL ((dense_matvec_f32_batch_kernel<4>), dim3 ((n + 3) / 4), dim3 (256), 0, st, Minv, ld, x, y, n);
+   else hipLaunchKernelGGL ((dense_matvec_f32_batch_kernel<8>), dim3 ((n + 3) / 4), dim3 (256), 0, st, Minv, ld, x, y, n);
 }

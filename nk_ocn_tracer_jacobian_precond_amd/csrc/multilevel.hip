@@ -1599,7 +1599,7 @@ void ml_apply (MlHierarchy &H, const double *r, double *z, hipStream_t st)
 // ================================================================ the cycle on K interleaved right-hand sides
 int ml_batch_prepare (MlHierarchy &H, int K)
 {
-   if (K != 2 && K != 4) return -1;
+   if (K != 2 && K != 4 && K != 8) return -1;
    if (H.batch_K >= K) return 0;
    for (MlLevel &V : H.lev) {
       for (double **p : { &V.bx, &V.bx2, &V.bb, &V.br }) {

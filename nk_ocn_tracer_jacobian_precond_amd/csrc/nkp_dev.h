@@ -122,6 +122,7 @@ void launch_gs_wave (const CsrDev &L, const ColBlocksDev &B, int b0, int b1, con
                      int r32, hipStream_t st);
 
 // ---------------------------------------------------------------- BLAS-1 style kernels
+#define NKP_BATCH_MAX 8            // right-hand sides per sweep at most (interleave widths 2, 4, 8)
 #define NKP_RED_BLOCKS 1024        // partial sums per reduction (fixed => deterministic)
 #define NKP_DOT_CHUNK 8
 

@@ -121,7 +121,7 @@ extern "C" int nkp_default_tuning (nkp_tuning *t)
    ENV_INT ("NKP_COLPIPE_MIN", col_pipe_min); ENV_FLAG ("NKP_LDSRES_EARLY", col_ldsres_early); ENV_FLAG ("NKP_COL_PACKED", col_ldsres_packed); ENV_FLAG ("NKP_COL_SORT_GROUPS", col_sort_groups); ENV_INT ("NKP_COL_LDSRES_MIN", col_ldsres_min);
    ENV_INT ("NKP_SPMV_VARIANT", spmv_variant); ENV_FLAG ("NKP_SPMV_COMPRESS", spmv_compress); ENV_INT ("NKP_SPMV_PIPE_MIN", spmv_pipe_min);
    ENV_POS ("NKP_SPMV_RUN", spmv_run); ENV_POS ("NKP_SPMV_WGS", spmv_wgs);
-   ENV_FLAG ("NKP_RHS_BATCH", rhs_batch); ENV_FLAG ("NKP_BATCH_SPMV_ROWS", batch_spmv_rows);
+   ENV_INT ("NKP_RHS_BATCH", rhs_batch); ENV_FLAG ("NKP_BATCH_SPMV_ROWS", batch_spmv_rows);
    ENV_POS ("NKP_PRECOND_STEPS", precond_steps); ENV_FLAG ("NKP_EQUIL", equil);
    ENV_FLAG ("NKP_DIST_OVERLAP", dist_overlap); ENV_FLAG ("NKP_DIST_RAS", dist_ras); ENV_FLAG ("NKP_DIST_ONE_REDUCE", dist_one_reduce);
    if (getenv ("NKP_FORCE_DIST")) t->force_dist = 1;
@@ -1240,8 +1240,8 @@ static void batch_apply (nkp_solver *s, int K, nkp_solver *const *mem, const boo
 {
    const int64_t ld = s->ld, n = s->n;
    hipStream_t st = s->stream;
-   const double *src[4] = { nullptr, nullptr, nullptr, nullptr };
-   double *dz[4] = { nullptr, nullptr, nullptr, nullptr }, *dw[4] = { nullptr, nullptr, nullptr, nullptr };
+   const double *src[NKP_BATCH_MAX] = {};
+   double *dz[NKP_BATCH_MAX] = {}, *dw[NKP_BATCH_MAX] = {};
    for (int k = 0; k < K; k++)
       if (mem[k] && running[k]) { src[k] = mem[k]->V + (int64_t) j * ld; dz[k] = mem[k]->Z + (int64_t) j * ld; dw[k] = mem[k]->w; }
    if (s->opt.precond == NKP_PRECOND_MULTILEVEL) {
@@ -1270,7 +1270,7 @@ static int fgmres_batch (nkp_solver *s, int K, int nact, nkp_solver *const *mem,
    for (int k = 0; k < nact; k++)
       if ((rc = fg_begin (mem[k], F[k]))) return rc;
    for (;;) {
-      bool running[4] = { false, false, false, false }, in_cycle[4] = { false, false, false, false };
+      bool running[NKP_BATCH_MAX] = {}, in_cycle[NKP_BATCH_MAX] = {};
       int nrun = 0;
       for (int k = 0; k < nact; k++) {
          if (F[k].finished) continue;
@@ -1319,25 +1319,35 @@ extern "C" int nkp_solve_batch_device (nkp_solver *s, int nrhs, const void *d_B,
       }
       return worst;
    }
-   for (int c0 = 0; c0 < nrhs; c0 += 4) {
-      const int nact = nrhs - c0 < 4 ? nrhs - c0 : 4;
+   int kmax = s->tune.rhs_batch >= 8 ? 8 : s->tune.rhs_batch >= 4 || s->tune.rhs_batch == 1 ? 4 : 2;      // widest interleave (nkp_tuning.rhs_batch: 1 = 4)
+   int nact = 0;
+   for (int c0 = 0; c0 < nrhs; c0 += nact) {
+      nact = nrhs - c0 < kmax ? nrhs - c0 : kmax;
       if (nact == 1) {
          const int status = nkp_solve_device (s, B + (size_t) c0 * (size_t) ldb, X + (size_t) c0 * (size_t) ldb, 0, berr ? berr + c0 : nullptr, iters ? iters + c0 : nullptr, relres ? relres + c0 : nullptr);
          if (status < 0) return status;
          if (sev_of (status) > sev_of (worst)) worst = status;
-         break;
+         continue;
       }
-      const int K = nact <= 2 ? 2 : 4;
+      int K = nact <= 2 ? 2 : nact <= 4 ? 4 : 8;
       int rc = batch_prepare (s, K);
+      // every further system in flight costs a set of work vectors: out of device memory => narrower interleave, then one at a time
+      while (rc == NKP_ENOMEM && K > 2) {
+         K /= 2;
+         kmax = K;
+         if (nact > K) nact = K;
+         rc = batch_prepare (s, K);
+      }
+      if (rc == NKP_ENOMEM) { kmax = 1; nact = 0; continue; }
       if (rc) return rc;
-      nkp_solver *mem[4] = { s, nullptr, nullptr, nullptr };
+      nkp_solver *mem[NKP_BATCH_MAX] = { s };
       for (int k = 1; k < K; k++) mem[k] = s->batch_members[(size_t) k - 1];
       for (int k = 0; k < nact; k++) {
          HIPCHK (hipMemsetAsync (mem[k]->x, 0, bytes, s->stream));
          HIPCHK (hipMemcpyAsync (mem[k]->b, B + (size_t) (c0 + k) * (size_t) ldb, bytes, hipMemcpyDeviceToDevice, s->stream));
          mem[k]->stagnated = false;
       }
-      FgmresState F[4];
+      FgmresState F[NKP_BATCH_MAX];
       if ((rc = fgmres_batch (s, K, nact, mem, F)) < 0) return rc;
       for (int k = 0; k < nact; k++) {
          // the verdict of one system, exactly as solve_resident gives it for a solve done alone

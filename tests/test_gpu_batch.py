@@ -85,3 +85,22 @@ def test_batch_zero_and_mixed_right_hand_sides(medium):
         for c in (0, 2):
             x1, i1 = s.solve(B[c])
             assert np.array_equal(X[c], x1) and infos[c]["iters"] == i1["iters"]
+
+
+@pytest.mark.parametrize("name,f32", [("medium", "1"), ("long_columns", "1"), ("tracers2", "0"), ("small", "1")])
+def test_eight_right_hand_sides_per_sweep(name, f32, medium, monkeypatch):
+    """nkp_tuning.rhs_batch = 8: groups of up to eight interleaved right-hand sides (9 = a group of eight and a single solve, 6 = one padded
+    group); every column still has the bits of its own solve."""
+    monkeypatch.setenv("NKP_ML_F32", f32)
+    p, blk, ci, cj, cnt = _case(name, medium)
+    rng = np.random.default_rng(21)
+    B = rng.standard_normal((9, p.flat_len))
+    B[5] *= 1e-4
+    with solver.NkpSolver(p.rowptr, p.colind, p.nzval, blk, coupled_tracer_cnt=cnt, col_i=ci, col_j=cj, rtol=1e-10, tuning=dict(rhs_batch=8)) as s:
+        single = [s.solve(B[c], raise_on_fail=False) for c in range(9)]
+        for nrhs in (6, 8, 9):
+            X, infos = s.solve_many(B[:nrhs], raise_on_fail=False)
+            for c in range(nrhs):
+                x1, i1 = single[c]
+                assert infos[c]["iters"] == i1["iters"] and infos[c]["relres"] == i1["relres"], (name, nrhs, c, infos[c], i1)
+                assert np.array_equal(X[c], x1), (name, nrhs, c, np.abs(X[c] - x1).max())

@@ -10,7 +10,8 @@ p = synth.generate(imt=320, jmt=384, km=60, adv="upwind3", hmix="isop", seed=0)
 blk = solver.column_blocks(p.col_start(), p.tracer_state_len, 1)
 ci, cj = solver.column_coords(p.ind_i, p.ind_j, p.col_start(), 1)
 g = torch.Generator(device="cuda"); g.manual_seed(1)
-B = torch.randn((4, p.flat_len), dtype=torch.float64, device="cuda", generator=g)
+R = int(os.environ.get("NKP_AB_R", "4"))
+B = torch.randn((R, p.flat_len), dtype=torch.float64, device="cuda", generator=g)
 X = torch.zeros_like(B)
 for arg in sys.argv[1:]:
     name, _, spec = arg.partition("=")
@@ -24,12 +25,12 @@ for arg in sys.argv[1:]:
         for rep in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             its = []
-            for k in range(4):
+            for k in range(R):
                 info = s.solve_device(B[k].data_ptr(), X[k].data_ptr())
                 its.append(info["iters"])
-            torch.cuda.synchronize(); out["single_ms"] = (time.perf_counter() - t0) / 4 * 1e3
+            torch.cuda.synchronize(); out["single_ms"] = (time.perf_counter() - t0) / R * 1e3
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            info = s.solve_batch_device(B.data_ptr(), X.data_ptr(), 4, p.flat_len)
-            torch.cuda.synchronize(); out["batch_ms_per_solve"] = (time.perf_counter() - t0) / 4 * 1e3
+            info = s.solve_batch_device(B.data_ptr(), X.data_ptr(), R, p.flat_len)
+            torch.cuda.synchronize(); out["batch_ms_per_solve"] = (time.perf_counter() - t0) / R * 1e3
         out["iters"] = its
         print(json.dumps(out), flush=True)
