@@ -44,7 +44,7 @@ static char *inout_fname = NULL;
 
 static int parse_cmd_line (int argc, char **argv)
 {
-   const char *usage_msg = "usage: jacobian_precond [-D dbg_lvl] [-n nprow[,npcol]] [-v vars] matrix_fname inout_fname";
+   const char *usage_msg = "usage: jacobian_precond [-D dbg_lvl] [-n nprow[,npcol]] [-v vars] matrix_fname inout_fname\n   vars: comma-separated variable names; NAME=SOLNAME reads the right-hand side from NAME and writes the solution to SOLNAME";
    int opt;
 
    while ((opt = getopt (argc, argv, "D:n:v:h")) != -1) {
@@ -106,6 +106,11 @@ static void trace (const char *what, const char *subname)
    }
 }
 
+// "-v RHS=SOL": the right-hand side is read from variable RHS and the solution written into variable SOL (which must exist with the
+// same shape; its land values are kept) -- the reference's TODO:1, "separate RHS and soln vectors in solve_AB".  A plain name is both.
+static std::string rhs_name (const char *tok) { const char *eq = strchr (tok, '='); return eq ? std::string (tok, (size_t) (eq - tok)) : std::string (tok); }
+static std::string sol_name (const char *tok) { const char *eq = strchr (tok, '='); return eq ? std::string (eq + 1) : std::string (tok); }
+
 // read each tracer of the group as a [km][jmt][imt] cube and flatten it into B
 // (reference get_B_global, src/solve_ABglobal.c:153-208)
 static int get_B_global (char **vars_per_solve, double *B)
@@ -118,17 +123,18 @@ static int get_B_global (char **vars_per_solve, double *B)
       return 1;
    }
    for (int t = 0; t < coupled_tracer_cnt; t++) {
+      const std::string vname = rhs_name (vars_per_solve[t]);
       size_t nelems = 0;
       if (dbg_lvl)
-         printf ("(%d) reading %s from %s\n", iam, vars_per_solve[t], inout_fname);
-      if (nkp_var_nelems (inout_fname, vars_per_solve[t], &nelems))
+         printf ("(%d) reading %s from %s\n", iam, vname.c_str (), inout_fname);
+      if (nkp_var_nelems (inout_fname, (char *) vname.c_str (), &nelems))
          return 1;
       if (nelems != (size_t) km * (size_t) jmt * (size_t) imt) {
-         fprintf (stderr, "(%d) %s: variable %s holds %zu values, expected km*jmt*imt = %zu\n", iam, subname, vars_per_solve[t], nelems,
+         fprintf (stderr, "(%d) %s: variable %s holds %zu values, expected km*jmt*imt = %zu\n", iam, subname, vname.c_str (), nelems,
                   (size_t) km * (size_t) jmt * (size_t) imt);
          return 1;
       }
-      if (get_var_3d_double (inout_fname, vars_per_solve[t], field_3d))
+      if (get_var_3d_double (inout_fname, (char *) vname.c_str (), field_3d))
          return 1;
       nkp_flatten_tracer (t, field_3d, B);
    }
@@ -149,12 +155,13 @@ static int put_B_global (char **vars_per_solve, double *B)
       return 1;
    }
    for (int t = 0; t < coupled_tracer_cnt; t++) {
-      if (get_var_3d_double (inout_fname, vars_per_solve[t], field_3d))
+      const std::string vname = sol_name (vars_per_solve[t]);
+      if (get_var_3d_double (inout_fname, (char *) vname.c_str (), field_3d))
          return 1;
       nkp_unflatten_tracer (t, B, field_3d);
       if (dbg_lvl)
-         printf ("(%d) writing %s to %s\n", iam, vars_per_solve[t], inout_fname);
-      if (put_var_3d_double (inout_fname, vars_per_solve[t], field_3d))
+         printf ("(%d) writing %s to %s\n", iam, vname.c_str (), inout_fname);
+      if (put_var_3d_double (inout_fname, (char *) vname.c_str (), field_3d))
          return 1;
    }
    free_3d_double (field_3d);

@@ -271,6 +271,32 @@ def test_cli_end_to_end(tmp_path, golden, exe):
             assert np.linalg.norm(xt - ref) / np.linalg.norm(ref) <= 1e-7
 
 
+def test_cli_separate_rhs_and_solution_variables(tmp_path, golden_by_name):
+    """`-v RHS=SOL` (the reference's TODO, first line: "separate RHS and soln vectors in solve_AB"): the right-hand side variable stays
+    as it was, the solution lands in the other variable (ocean cells only), and equals what the in-place run writes."""
+    g = golden_by_name("penta_12x10x6")
+    v = g.varnames[0]
+    src = nc3.NcFile(g.tracer_path)
+    dims = {"nlon": g.imt, "nlat": g.jmt, "z_t": g.km}
+    fill = {"_FillValue": np.float64(synth.FILL_DOUBLE)}
+    sol0 = np.full((g.km, g.jmt, g.imt), 7.0)
+    two = str(tmp_path / "two.nc")
+    nc3.write(two, dims, [(v, ["z_t", "nlat", "nlon"], src.get(v), fill), (v + "_SOL", ["z_t", "nlat", "nlon"], sol0, fill)])
+    one = str(tmp_path / "one.nc")
+    nc3.write(one, dims, [(v, ["z_t", "nlat", "nlon"], src.get(v), fill)])
+    for path, spec in ((two, f"{v}={v}_SOL"), (one, v)):
+        r = subprocess.run([os.path.join(BIN, "solve_ABglobal"), "-v", spec, g.matrix_path, path], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout
+    a, b = nc3.NcFile(two), nc3.NcFile(one)
+    ocean = np.zeros((g.km, g.jmt, g.imt), bool)
+    ocean[g.ind_k, g.ind_j, g.ind_i] = True
+    assert a.get(v).tobytes() == src.get(v).tobytes()                                   # the right-hand side is untouched
+    assert np.array_equal(a.get(v + "_SOL")[ocean], b.get(v)[ocean])                    # same solution as the in-place run
+    assert np.all(a.get(v + "_SOL")[~ocean] == 7.0)                                      # the target's land values survive
+    r = subprocess.run([os.path.join(BIN, "solve_ABglobal"), "-v", f"{v}=NO_SUCH_VAR", g.matrix_path, two], capture_output=True, text=True)
+    assert r.returncode != 0
+
+
 def test_cli_running_out_of_names(tmp_path, golden_by_name):
     g = golden_by_name("pair_8x8x5")
     dst = str(tmp_path / "B.nc")
