@@ -130,6 +130,7 @@ typedef struct nkp_tuning {
                                 Off by default: the identity assumes an orthonormal basis, which one Gram-Schmidt pass keeps only
                                 to 1e-6 or so, and the solve pays for it (2 ranks, 40x46x20: 48 iterations against 45) -- more than
                                 the 20-30 us allreduce it saves per 3 ms step */
+   int ml_huge_from;         /* NKP_ML_HUGE_FROM (-1 = never): 8 x 8 groups from that level on */
    int col_ldsres_min;       /* NKP_COL_LDSRES_MIN (0 = automatic): fewest columns of a level served by the LDS-resident column kernels */
    int col_sort_groups;      /* NKP_COL_SORT_GROUPS (1): packed column layout groups a colour's columns by length (less zero padding) */
    int batch_spmv_rows;      /* NKP_BATCH_SPMV_ROWS (1): batched SpMV stages the (value, column) stream in LDS and lets each row's lane gather

@@ -735,7 +735,7 @@ struct SetupTimes { double low = 0.0, graph = 0.0, galerkin = 0.0; };
 
 // knobs of the hierarchy construction (nkp_tuning; defaults are the measured best)
 struct PlanKnobs {
-   int split = 1, pocket = 4, big_from = -3;
+   int split = 1, pocket = 4, big_from = -3, huge_from = -1;
    double theta = 0.0, tau = 0.01;
 };
 
@@ -747,6 +747,7 @@ PlanKnobs plan_knobs (const nkp_tuning &t)
    k.theta = t.ml_theta;
    k.tau = t.ml_tau;
    k.big_from = t.ml_big_from;
+   k.huge_from = t.ml_huge_from;
    return k;
 }
 
@@ -817,6 +818,7 @@ int group_shift (const PlanKnobs &K, int level, int ncol_level0, int tracer_cnt)
 {
    int bf = K.big_from;
    if (bf == -3) bf = ncol_level0 / (tracer_cnt > 0 ? tracer_cnt : 1) >= 200000 ? -1 : 3;
+   if (K.huge_from >= 0 && level >= K.huge_from) return 3;          // 8 x 8 groups (A/B knob ml_huge_from)
    return (bf >= 0 && level >= bf) ? 2 : 1;
 }
 

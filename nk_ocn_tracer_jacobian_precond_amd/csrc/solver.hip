@@ -87,7 +87,7 @@ static void builtin_tuning (nkp_tuning *t)
    t->col_group = 8; t->col_pipe_min = 0; t->col_ldsres_early = 0; t->col_ldsres_packed = 1; t->col_sort_groups = 1;
    t->spmv_variant = 4; t->spmv_compress = 0; t->spmv_pipe_min = 1024; t->spmv_run = 1; t->spmv_wgs = 256;
    t->rhs_batch = 1; t->batch_spmv_rows = 1; t->precond_steps = 0; t->equil = -1; t->dist_overlap = 1; t->dist_ras = 1; t->dist_one_reduce = 0; t->force_dist = 0; t->setup_threads = 0; t->plan_times = 0;
-   t->ml_drop_intertracer = 0;
+   t->ml_drop_intertracer = 0; t->ml_huge_from = -1;
 }
 
 const nkp_tuning &nkp_builtin_tuning ()
@@ -118,7 +118,7 @@ extern "C" int nkp_default_tuning (nkp_tuning *t)
    ENV_INT ("NKP_COL_LDSRES", col_ldsres); ENV_FLAG ("NKP_COLSTREAM", col_stream); ENV_INT ("NKP_COLSTREAM_MIN", col_stream_min);
    if ((e = getenv ("NKP_COLSTREAM_GW")) && *e) t->col_stream_gw = atoi (e) == 64 ? 64 : 32;
    ENV_INT ("NKP_COLWAVE_MAX", col_wave_max); ENV_FLAG ("NKP_COL_W3", col_w3); ENV_INT ("NKP_COLGROUP", col_group);
-   ENV_INT ("NKP_COLPIPE_MIN", col_pipe_min); ENV_FLAG ("NKP_LDSRES_EARLY", col_ldsres_early); ENV_FLAG ("NKP_COL_PACKED", col_ldsres_packed); ENV_FLAG ("NKP_COL_SORT_GROUPS", col_sort_groups); ENV_INT ("NKP_COL_LDSRES_MIN", col_ldsres_min);
+   ENV_INT ("NKP_COLPIPE_MIN", col_pipe_min); ENV_FLAG ("NKP_LDSRES_EARLY", col_ldsres_early); ENV_FLAG ("NKP_COL_PACKED", col_ldsres_packed); ENV_FLAG ("NKP_COL_SORT_GROUPS", col_sort_groups); ENV_INT ("NKP_COL_LDSRES_MIN", col_ldsres_min); ENV_INT ("NKP_ML_HUGE_FROM", ml_huge_from);
    ENV_INT ("NKP_SPMV_VARIANT", spmv_variant); ENV_FLAG ("NKP_SPMV_COMPRESS", spmv_compress); ENV_INT ("NKP_SPMV_PIPE_MIN", spmv_pipe_min);
    ENV_POS ("NKP_SPMV_RUN", spmv_run); ENV_POS ("NKP_SPMV_WGS", spmv_wgs);
    ENV_INT ("NKP_RHS_BATCH", rhs_batch); ENV_FLAG ("NKP_BATCH_SPMV_ROWS", batch_spmv_rows);

@@ -55,7 +55,7 @@ class NkpTuning(C.Structure):
         ("col_w3", C.c_int), ("col_group", C.c_int), ("col_pipe_min", C.c_int), ("col_ldsres_early", C.c_int), ("col_ldsres_packed", C.c_int),
         ("spmv_variant", C.c_int), ("spmv_compress", C.c_int), ("spmv_pipe_min", C.c_int), ("spmv_run", C.c_int), ("spmv_wgs", C.c_int),
         ("rhs_batch", C.c_int), ("precond_steps", C.c_int), ("equil", C.c_int), ("dist_overlap", C.c_int), ("dist_ras", C.c_int), ("force_dist", C.c_int),
-        ("setup_threads", C.c_int), ("plan_times", C.c_int), ("ml_drop_intertracer", C.c_int), ("dist_one_reduce", C.c_int), ("col_ldsres_min", C.c_int), ("col_sort_groups", C.c_int), ("batch_spmv_rows", C.c_int),
+        ("setup_threads", C.c_int), ("plan_times", C.c_int), ("ml_drop_intertracer", C.c_int), ("dist_one_reduce", C.c_int), ("ml_huge_from", C.c_int), ("col_ldsres_min", C.c_int), ("col_sort_groups", C.c_int), ("batch_spmv_rows", C.c_int),
     ]
 
 
